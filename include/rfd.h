@@ -1,0 +1,233 @@
+/*
+ * rfd.h -- C ABI of librfd_hip.so: the MI355X-native (gfx950) replacement of the detection stage of
+ * okieraised/rs-face-detection, i.e. of
+ *     RetinaFaceDetection::call(&self, image:&Mat, is_debug) -> (Array2<f32>[K,5], Array3<f32>[K,5,2])
+ *     (reference src/pipeline/module/face_detection.rs:496), invoked from
+ *     FacePipeline::extract (src/pipeline/face_pipeline/pipeline.rs:198).
+ *
+ * The reference ships a 640x640 f32 tensor to a Triton server (face_detection.rs:279) and decodes
+ * the 9 returned head tensors on the CPU.  Here preprocess, the RetinaFace network, decode, sort,
+ * NMS and rescale all run on the GPU as HIP kernels; this header is what a Rust `extern "C"` block
+ *  binds.  The only native ABI the reference itself declares is `_nms`
+ * (src/rcnn/gpu_nms.hpp:7); a compatible symbol is exported too.
+ *
+ * Conventions (mirroring `_nms`): the caller allocates every input and output buffer; the context
+ * owns device weights, workspaces, streams.  Every function returns 0 on success or a negative
+ * rfd_status; rfd_last_error() returns a message for the last failure on the calling thread.
+ * There is NO CPU fallback: without a usable HIP device rfd_create fails with RFD_ERR_NO_DEVICE.
+ * A context is not re-entrant (one stream + workspace); use one context per thread.
+ */
+#ifndef RFD_H
+#define RFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFD_VERSION 1
+
+#if defined(__GNUC__)
+#define RFD_API __attribute__((visibility("default")))
+#else
+#define RFD_API
+#endif
+
+typedef enum rfd_status {
+    RFD_OK = 0,
+    RFD_ERR_INVALID_ARG = -1, /* null pointer, bad shape, channels != 3 (reference: OpenCV error / at_2d failure, face_detection.rs:137,226) */
+    RFD_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at creation */
+    RFD_ERR_HIP = -3,         /* a HIP call or kernel failed (reference: Triton RPC failure, face_detection.rs:282) */
+    RFD_ERR_CAPACITY = -4,    /* batch / frame / detections exceed the configured capacity */
+    RFD_ERR_STATE = -5,       /* weights not initialised (reference: empty model config, face_detection.rs:239) */
+    RFD_ERR_IO = -6           /* weight file could not be read / written */
+} rfd_status;
+
+typedef enum rfd_backbone {
+    RFD_BACKBONE_R50 = 0,     /* RetinaFace ResNet-50 + FPN + SSH */
+    RFD_BACKBONE_MNET025 = 1  /* RetinaFace MobileNet-0.25 (same head/anchor contract) */
+} rfd_backbone;
+
+/*
+ * Mirrors FaceDetectionConfig (src/pipeline/face_pipeline/config.rs:13-33) and the arguments of
+ * RetinaFaceDetection::new (face_detection.rs:41-49): image_size is (w,h); the Triton client /
+ * model-config / model-name arguments are gone (the network runs in-process); device, batch
+ * capacity and output capacity are new.
+ */
+typedef struct rfd_config {
+    int image_w;                /* config.rs:26 image_size.0, default 640 */
+    int image_h;                /* config.rs:26 image_size.1, default 640 */
+    int max_batch_size;         /* config.rs:28 (reference: 1); frames per rfd_detect_batch call */
+    float confidence_threshold; /* config.rs:29, default 0.7; keep rows with score >= threshold */
+    float iou_threshold;        /* config.rs:30, default 0.45; suppress on IoU > threshold */
+    int device_id;              /* HIP device ordinal */
+    int max_det;                /* capacity (rows per image) of the output slabs; default 1024 */
+    int max_src_w;              /* largest source frame the context must stage; default 3840 */
+    int max_src_h;              /* default 2160 */
+    int backbone;               /* rfd_backbone */
+    int reserved[6];
+} rfd_config;
+
+/* A decoded source frame: HxWx3 u8, BGR, row stride in bytes (an OpenCV Mat CV_8UC3,
+ * as produced by byte_data_to_opencv, src/utils/utils.rs:8-52). */
+typedef struct rfd_image {
+    const uint8_t *data;
+    int height;
+    int width;
+    ptrdiff_t stride;
+} rfd_image;
+
+/*
+ * Caller-allocated outputs for n frames.  Row layout equals the reference's return value
+ * (face_detection.rs:432-464, 473-493): boxes row = x1,y1,x2,y2,score in SOURCE-image pixels,
+ * rows in descending score (kept order); landmarks row = 5 x (x,y).
+ *   boxes     [n][max_det][5]  f32
+ *   landmarks [n][max_det][10] f32
+ *   count     [n] i32 = min(K, max_det)
+ *   total     [n] i32 = K, the untruncated number of detections (may be NULL)
+ */
+typedef struct rfd_dets {
+    float *boxes;
+    float *landmarks;
+    int32_t *count;
+    int32_t *total;
+} rfd_dets;
+
+/* Per-call stage timings measured with HIP events on the context's stream (milliseconds). */
+typedef struct rfd_stats {
+    float ms_h2d;
+    float ms_preprocess;
+    float ms_network;
+    float ms_decode;
+    float ms_sort;
+    float ms_nms;
+    float ms_d2h;
+    float ms_total;
+    int64_t candidates; /* rows with score >= threshold, summed over the batch */
+    int64_t detections; /* kept rows, summed over the batch */
+    int64_t reserved[4];
+} rfd_stats;
+
+typedef struct rfd_ctx rfd_ctx;
+
+/* ---- lifecycle (replaces RetinaFaceDetection::new, face_detection.rs:41-129, and the Triton
+ *      channel set-up of FacePipeline::new, pipeline.rs:64-128) ---- */
+RFD_API void rfd_config_default(rfd_config *cfg);
+RFD_API int rfd_create(const rfd_config *cfg, rfd_ctx **out);
+RFD_API void rfd_destroy(rfd_ctx *ctx);
+RFD_API const char *rfd_last_error(void);
+RFD_API int rfd_version(void);
+
+/* ---- network graph description (host only: works without a GPU).  The reference never sees the
+ *      graph (it only knows the Triton model name, config.rs:25); these calls expose the
+ *      build-defined graph so that tests can rebuild it layer by layer. ---- */
+typedef struct rfd_graph rfd_graph;
+typedef struct rfd_layer_desc {
+    char name[64];
+    int cin, cout, kh, kw, stride, pad;
+    int has_affine; /* per-channel scale/shift + ReLU applied after the residual add (or the pool) */
+    int reserved[4];
+} rfd_layer_desc;
+typedef struct rfd_op_desc {
+    int kind;  /* 0: conv0 7x7/2 + bias + ReLU, 1: maxpool 3x3/2 (+ affine + ReLU), 2: conv */
+    int layer; /* weights used (kind 1: the layer whose affine is applied) */
+    int in, out, out2, outf, res; /* tensor ids, -1 = none: out = bf16 result, out2 = relu(affine(v)),
+                                     outf = f32 result (heads), res = residual input */
+    int relu, res_up2, res_post, head_softmax, y_coff;
+    double macs; /* multiply-accumulates per image */
+    int reserved[4];
+} rfd_op_desc;
+typedef struct rfd_tensor_desc {
+    int channels, height, width;
+    int is_f32, buffer, is_input, head_level; /* head_level: 1,2,3 = stride 32,16,8 head tensor */
+    int reserved[4];
+} rfd_tensor_desc;
+RFD_API int rfd_graph_create(int backbone, int image_w, int image_h, rfd_graph **out);
+RFD_API void rfd_graph_destroy(rfd_graph *g);
+RFD_API int rfd_graph_counts(const rfd_graph *g, int *layers, int *ops, int *tensors, int *buffers);
+RFD_API int rfd_graph_layer(const rfd_graph *g, int idx, rfd_layer_desc *d);
+RFD_API int rfd_graph_op(const rfd_graph *g, int idx, rfd_op_desc *d);
+RFD_API int rfd_graph_tensor(const rfd_graph *g, int idx, rfd_tensor_desc *d);
+RFD_API double rfd_graph_macs(const rfd_graph *g);            /* conv MACs per image */
+RFD_API double rfd_graph_workspace_bytes(const rfd_graph *g); /* planned activation bytes per image */
+
+/* ---- weights (replace Triton's model repository for "face_detection_retina", config.rs:25) ---- */
+RFD_API int rfd_init_synthetic_weights(rfd_ctx *ctx, uint64_t seed);
+RFD_API int rfd_num_layers(const rfd_ctx *ctx);
+/* weights [cout][kh][kw][cin] f32 (values as stored on device, i.e. bf16-rounded), bias [cout];
+ * BatchNorm is expected to be folded into weights/bias by the caller. */
+RFD_API int rfd_get_layer_weights(rfd_ctx *ctx, int idx, float *weights, float *bias);
+RFD_API int rfd_set_layer_weights(rfd_ctx *ctx, int idx, const float *weights, const float *bias);
+/* the post-add affine (scale, shift per output channel) of layers with has_affine */
+RFD_API int rfd_get_layer_affine(rfd_ctx *ctx, int idx, float *scale, float *shift);
+RFD_API int rfd_set_layer_affine(rfd_ctx *ctx, int idx, const float *scale, const float *shift);
+
+/* ---- the hot path: replaces RetinaFaceDetection::call (face_detection.rs:496-513) for a batch
+ *      of frames.  Host buffers in, host buffers out; synchronous. ---- */
+RFD_API int rfd_detect_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_dets *out);
+
+/* Same, with every `data` pointer of imgs[] and every pointer of `out` in DEVICE memory (frames
+ * already resident in HBM, detections left in HBM for a following RCCL gather).  The imgs[] array
+ * itself is host memory.  Enqueued on the context's stream; returns after the stream has drained
+ * unless `async` is non-zero (then call rfd_sync before reading results / reusing buffers). */
+RFD_API int rfd_detect_batch_device(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_dets *out, int async);
+RFD_API int rfd_sync(rfd_ctx *ctx);
+
+/* ---- stage-level entry points (parity tests; each mirrors one reference stage) ---- */
+
+/* _preprocess + tensorise (face_detection.rs:131-198, 220-232) for n frames.
+ * det_img [n][image_h][image_w][3] u8 (may be NULL), tensor [n][3][image_h][image_w] f32 R,G,B
+ * planes raw 0..255 (may be NULL), det_scale [n] f32.  Host pointers. */
+RFD_API int rfd_preprocess(rfd_ctx *ctx, const rfd_image *imgs, int n, uint8_t *det_img, float *tensor,
+                   float *det_scale);
+
+/* The network: tensor [n][3][image_h][image_w] f32 (the reference's Triton input contract,
+ * face_detection.rs:220-277) -> 9 head tensors, f32, NCHW, in the reference's slot order
+ * 32,16,8 x (cls [n,4,h,w], bbox [n,8,h,w], lmk [n,20,h,w]) (face_detection.rs:286-312, 319-407).
+ * Host pointers. */
+RFD_API int rfd_forward(rfd_ctx *ctx, const float *tensor, int n, float *const heads[9]);
+
+/* Everything after the network (face_detection.rs:319-493) on caller-supplied head tensors
+ * (same contract as rfd_forward's outputs), det_scale [n].  Host pointers.
+ * gidx (may be NULL) [n][max_det] i32 receives the global anchor index of every kept row. */
+RFD_API int rfd_decode_nms(rfd_ctx *ctx, const float *const heads[9], int n, const float *det_scale,
+                   rfd_dets *out, int32_t *gidx);
+
+/* Greedy NMS on boxes pre-sorted by score descending: the contract of the reference's (never
+ * built) CUDA entry point `_nms` (src/rcnn/nms_kernel.cu:91-144, src/rcnn/gpu_nms.hpp:7) with the
+ * live path's survivor rule (src/processing/nms.rs:58).  boxes: host [boxes_num][boxes_dim>=4]
+ * f32; keep: capacity boxes_num.  Returns a status (the reference returns void and prints). */
+RFD_API int rfd_nms_sorted(rfd_ctx *ctx, int32_t *keep, int *num_out, const float *boxes, int boxes_num,
+                   int boxes_dim, float thresh);
+
+/* Drop-in for the reference's declaration (gpu_nms.hpp:7): uses a process-wide context on
+ * device_id, prints nothing, leaves *num_out = -1 on failure. */
+RFD_API void _nms(int32_t *keep, int *num_out, float *boxes, int boxes_num, int boxes_dim, float thresh,
+          int device_id);
+
+/* ---- introspection ---- */
+RFD_API int rfd_get_stats(rfd_ctx *ctx, rfd_stats *stats);
+RFD_API int rfd_get_config(const rfd_ctx *ctx, rfd_config *cfg);
+/* confidence_threshold / iou_threshold are plain fields of the reference's struct
+ * (face_detection.rs:26-27); they may be changed between calls. */
+RFD_API int rfd_set_thresholds(rfd_ctx *ctx, float confidence_threshold, float iou_threshold);
+/* Per-launch profiling of the network: when enabled, every network op is bracketed by HIP events on
+ * the context's stream.  rfd_get_conv_profile returns, for the last synchronous detect/forward call,
+ * the summed duration (ms) of the implicit-GEMM conv launches, the FLOPs they performed and their
+ * number; rfd_get_op_profile copies the per-op durations (ms) and returns the op count. */
+RFD_API int rfd_set_profiling(rfd_ctx *ctx, int enable);
+RFD_API int rfd_get_conv_profile(rfd_ctx *ctx, float *ms_conv, double *flops_conv, int *launches);
+RFD_API int rfd_get_op_profile(rfd_ctx *ctx, float *ms, int cap);
+
+/* ---- test hooks (not part of the drop-in surface): raw access to a network tensor (device layout:
+ *      NHWC, bf16 or f32 as rfd_tensor_desc says; n * C*H*W elements) and partial execution of the
+ *      op list [first_op, last_op] (last_op < 0: to the end), so every op can be checked in isolation. */
+RFD_API int rfd_debug_tensor_io(rfd_ctx *ctx, int tensor_id, int n, void *host, int write);
+RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFD_H */

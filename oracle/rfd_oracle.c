@@ -1,0 +1,458 @@
+/*
+ * rfd_oracle.c -- CPU restatement (plain C) of the reference's RetinaFace detection hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (librfd_hip.so, the python host mirror) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and there only as the checker / the timed CPU baseline.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference (okieraised/rs-face-detection, Rust) cannot be
+ * built here (no rustc/cargo, no OpenCV, no Triton) and its tests assert nothing and hold no
+ * expected outputs.  This restatement is pinned only by known answers
+ * derived by hand from the reference's formulas on the literal inputs of the reference's own
+ * print-only tests (tests/golden/kat_*.json).  The OpenCV bilinear resize
+ * (third party: opencv crate 0.92.0 -> system OpenCV 4.x, call site face_detection.rs:156) is
+ * restated from OpenCV's published algorithm and is unpinned as well.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * Arithmetic is IEEE f32 in the written operation order: compile with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define RFD_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * Anchors: src/processing/generate_anchors.rs
+ * ------------------------------------------------------------------------------------------ */
+
+/* _whctrs, generate_anchors.rs:20-26 */
+static void whctrs(const float a[4], float *w, float *h, float *xc, float *yc)
+{
+    *w = a[2] - a[0] + 1.0f;
+    *h = a[3] - a[1] + 1.0f;
+    *xc = a[0] + 0.5f * (*w - 1.0f);
+    *yc = a[1] + 0.5f * (*h - 1.0f);
+}
+
+/* _mkanchors, generate_anchors.rs:28-39 (one row) */
+static void mkanchor(float ws, float hs, float xc, float yc, float out[4])
+{
+    out[0] = xc - 0.5f * (ws - 1.0f);
+    out[1] = yc - 0.5f * (hs - 1.0f);
+    out[2] = xc + 0.5f * (ws - 1.0f);
+    out[3] = yc + 0.5f * (hs - 1.0f);
+}
+
+/*
+ * generate_anchors2 (dense_anchor = false), generate_anchors.rs:61-93, with _ratio_enum :141-148
+ * and _scale_enum :151-157.  out: [n_ratios * n_scales][4], ratio-major.
+ */
+RFD_API int rfd_oracle_generate_anchors2(int base_size, const float *ratios, int n_ratios,
+                                         const float *scales, int n_scales, float *out)
+{
+    float base[4] = {1.0f - 1.0f, 1.0f - 1.0f, (float)base_size - 1.0f, (float)base_size - 1.0f};
+    int n = 0;
+    for (int r = 0; r < n_ratios; ++r) {
+        float w, h, xc, yc;
+        whctrs(base, &w, &h, &xc, &yc);
+        float size = w * h;
+        float size_ratio = size / ratios[r];
+        float ws = roundf(sqrtf(size_ratio)); /* f32::round = half away from zero */
+        float hs = ws * ratios[r];
+        float ra[4];
+        mkanchor(ws, hs, xc, yc, ra);
+        float rw, rh, rxc, ryc;
+        whctrs(ra, &rw, &rh, &rxc, &ryc);
+        for (int s = 0; s < n_scales; ++s) {
+            mkanchor(rw * scales[s], rh * scales[s], rxc, ryc, out + 4 * n);
+            ++n;
+        }
+    }
+    return n;
+}
+
+/*
+ * generate_anchors_fpn2 with the production config of face_detection.rs:55-80:
+ * strides sorted descending (generate_anchors.rs:123-124) = 32,16,8; base 16; ratio 1;
+ * scales {32:(32,16), 16:(8,4), 8:(2,1)}.  out: [3][2][4].
+ */
+RFD_API void rfd_oracle_anchors_fpn(float *out)
+{
+    static const float ratio[1] = {1.0f};
+    static const float scales[3][2] = {{32.0f, 16.0f}, {8.0f, 4.0f}, {2.0f, 1.0f}};
+    for (int l = 0; l < 3; ++l)
+        rfd_oracle_generate_anchors2(16, ratio, 1, scales[l], 2, out + l * 8);
+}
+
+/* rcnn::anchors::anchors, src/rcnn/anchors.rs:3-21.  out: [height][width][a][4]. */
+RFD_API void rfd_oracle_anchor_plane(int height, int width, int stride, const float *base, int a,
+                                     float *out)
+{
+    for (int iw = 0; iw < width; ++iw) {
+        float sw = (float)(iw * stride);
+        for (int ih = 0; ih < height; ++ih) {
+            float sh = (float)(ih * stride);
+            for (int k = 0; k < a; ++k) {
+                float *o = out + (((size_t)ih * width + iw) * a + k) * 4;
+                o[0] = base[k * 4 + 0] + sw;
+                o[1] = base[k * 4 + 1] + sh;
+                o[2] = base[k * 4 + 2] + sw;
+                o[3] = base[k * 4 + 3] + sh;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Box / landmark decode: src/pipeline/module/face_detection.rs:516-570,
+ * clip: src/processing/bbox_transform.rs:27-45
+ * ------------------------------------------------------------------------------------------ */
+
+/* bbox_pred, face_detection.rs:516-549 (first 4 columns). boxes,deltas,out: [n][4]. */
+RFD_API void rfd_oracle_bbox_pred(const float *boxes, const float *deltas, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float *b = boxes + 4 * i, *d = deltas + 4 * i;
+        float w = b[2] - b[0] + 1.0f;               /* :522 */
+        float h = b[3] - b[1] + 1.0f;               /* :523 */
+        float cx = b[0] + 0.5f * (w - 1.0f);        /* :524 */
+        float cy = b[1] + 0.5f * (h - 1.0f);        /* :525 */
+        float pcx = d[0] * w + cx;                  /* :532 */
+        float pcy = d[1] * h + cy;                  /* :533 */
+        float pw = expf(d[2]) * w;                  /* :534 (f32::exp -> libm expf) */
+        float ph = expf(d[3]) * h;                  /* :535 */
+        out[4 * i + 0] = pcx - 0.5f * (pw - 1.0f);  /* :539 */
+        out[4 * i + 1] = pcy - 0.5f * (ph - 1.0f);  /* :540 */
+        out[4 * i + 2] = pcx + 0.5f * (pw - 1.0f);  /* :541 */
+        out[4 * i + 3] = pcy + 0.5f * (ph - 1.0f);  /* :542 */
+    }
+}
+
+/* landmark_pred, face_detection.rs:551-570. boxes [n][4], deltas/out [n][5][2]. */
+RFD_API void rfd_oracle_landmark_pred(const float *boxes, const float *deltas, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float *b = boxes + 4 * i;
+        float w = b[2] - b[0] + 1.0f;
+        float h = b[3] - b[1] + 1.0f;
+        float cx = b[0] + 0.5f * (w - 1.0f);
+        float cy = b[1] + 0.5f * (h - 1.0f);
+        for (int p = 0; p < 5; ++p) {
+            out[i * 10 + 2 * p + 0] = deltas[i * 10 + 2 * p + 0] * w + cx; /* :565 */
+            out[i * 10 + 2 * p + 1] = deltas[i * 10 + 2 * p + 1] * h + cy; /* :566 */
+        }
+    }
+}
+
+/* Rust f32::min / f32::max: if one operand is NaN the other is returned. */
+static float rmin(float a, float b) { return fminf(a, b); }
+static float rmax(float a, float b) { return fmaxf(a, b); }
+
+/* clip_boxes, bbox_transform.rs:27-45: v.min(hi).max(0). boxes [n][4] in place. */
+RFD_API void rfd_oracle_clip_boxes(float *boxes, int n, int im_h, int im_w)
+{
+    float width = (float)im_w - 1.0f, height = (float)im_h - 1.0f;
+    for (int i = 0; i < n; ++i) {
+        float *b = boxes + 4 * i;
+        b[0] = rmax(rmin(b[0], width), 0.0f);
+        b[1] = rmax(rmin(b[1], height), 0.0f);
+        b[2] = rmax(rmin(b[2], width), 0.0f);
+        b[3] = rmax(rmin(b[3], height), 0.0f);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stable argsort descending: src/utils/utils.rs:87-95 (Vec::sort_by is a stable merge sort)
+ * ------------------------------------------------------------------------------------------ */
+static void merge_sort_desc(const float *key, int *idx, int *tmp, int n)
+{
+    if (n < 2) return;
+    int h = n / 2;
+    merge_sort_desc(key, idx, tmp, h);
+    merge_sort_desc(key, idx + h, tmp, n - h);
+    int i = 0, j = h, k = 0;
+    while (i < h && j < n) {
+        /* take right only if strictly greater: ties keep the earlier (left) element first */
+        if (key[idx[j]] > key[idx[i]]) tmp[k++] = idx[j++];
+        else tmp[k++] = idx[i++];
+    }
+    while (i < h) tmp[k++] = idx[i++];
+    while (j < n) tmp[k++] = idx[j++];
+    memcpy(idx, tmp, (size_t)n * sizeof(int));
+}
+
+RFD_API void rfd_oracle_argsort_desc(const float *scores, int n, int *order)
+{
+    int *tmp = (int *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    for (int i = 0; i < n; ++i) order[i] = i;
+    merge_sort_desc(scores, order, tmp, n);
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Greedy NMS: src/processing/nms.rs:3-65.  dets [n][5] = x1,y1,x2,y2,score.
+ * Returns the number kept; keep[] = indices into dets in kept order.
+ * The survivor rule is `ovr <= thresh` (:58): a NaN overlap is suppressed.
+ * ------------------------------------------------------------------------------------------ */
+RFD_API int rfd_oracle_nms(const float *dets, int n, float thresh, int *keep)
+{
+    if (n <= 0) return 0;
+    float *sc = (float *)malloc((size_t)n * sizeof(float));
+    int *order = (int *)malloc((size_t)n * sizeof(int));
+    for (int i = 0; i < n; ++i) sc[i] = dets[5 * i + 4];
+    rfd_oracle_argsort_desc(sc, n, order); /* :5-6 (stable; a no-op on pre-sorted input) */
+    int m = n, nk = 0;
+    while (m > 0) {
+        int i = order[0];
+        keep[nk++] = i; /* :11-12 */
+        const float *bi = dets + 5 * i;
+        float area_i = (bi[2] - bi[0] + 1.0f) * (bi[3] - bi[1] + 1.0f); /* :46 */
+        int m2 = 0;
+        for (int t = 1; t < m; ++t) {
+            int j = order[t];
+            const float *bj = dets + 5 * j;
+            float xx1 = rmax(bi[0], bj[0]); /* :14-19 */
+            float yy1 = rmax(bi[1], bj[1]);
+            float xx2 = rmin(bi[2], bj[2]);
+            float yy2 = rmin(bi[3], bj[3]);
+            float w = xx2 - xx1 + 1.0f;     /* :39 */
+            float h = yy2 - yy1 + 1.0f;     /* :40 */
+            w = rmax(0.0f, w);              /* :42 */
+            h = rmax(0.0f, h);              /* :43 */
+            float inter = w * h;            /* :45 */
+            float area_j = (bj[2] - bj[0] + 1.0f) * (bj[3] - bj[1] + 1.0f); /* :50 */
+            float ovr = inter / (area_i + area_j - inter);                  /* :54 */
+            if (ovr <= thresh) order[m2++] = j;                             /* :58-61 */
+        }
+        m = m2;
+    }
+    free(sc);
+    free(order);
+    return nk;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * _forward after the network: face_detection.rs:319-470, and _postprocess :473-493.
+ *
+ * heads[9]: per level (stride 32,16,8) cls [2A,h,w], bbox [4A,h,w], lmk [10A,h,w], f32, NCHW with
+ * N = 1 (the reference's Triton output contract, face_detection.rs:286-312), A = 2.
+ * net_h, net_w: the network input size (im_info, :213-218; clip bound :373).
+ * det_scale <= 0 means "do not rescale" (skip _postprocess).
+ * Outputs: det [K][5], lmk [K][5][2], gidx [K] = global anchor row index of each kept detection
+ * (level offset + (h*W+w)*A+a).  cap = capacity in rows of the output buffers.
+ * Returns K (the true count, which may exceed cap; only min(K,cap) rows are written), or -1.
+ * n_candidates (optional) receives the number of rows with score >= conf_thr.
+ * ------------------------------------------------------------------------------------------ */
+RFD_API int rfd_oracle_decode_nms(const float *const *heads, int net_h, int net_w, float conf_thr,
+                                  float iou_thr, float det_scale, float *det, float *lmk,
+                                  int *gidx, int cap, int *n_candidates)
+{
+    static const int strides[3] = {32, 16, 8};
+    const int A = 2;
+    float base[3 * 2 * 4];
+    rfd_oracle_anchors_fpn(base);
+
+    int total = 0;
+    for (int l = 0; l < 3; ++l) total += (net_h / strides[l]) * (net_w / strides[l]) * A;
+    float *props = (float *)malloc((size_t)total * 4 * sizeof(float));
+    float *scores = (float *)malloc((size_t)total * sizeof(float));
+    float *lmks = (float *)malloc((size_t)total * 10 * sizeof(float));
+    int *gids = (int *)malloc((size_t)total * sizeof(int));
+    if (!props || !scores || !lmks || !gids) return -1;
+
+    int n = 0, goff = 0;
+    for (int l = 0; l < 3; ++l) { /* :319 */
+        const int s = strides[l];
+        const int fh = net_h / s, fw = net_w / s, k = fh * fw;
+        const float *cls = heads[3 * l + 0], *bbx = heads[3 * l + 1], *lmd = heads[3 * l + 2];
+        float *plane = (float *)malloc((size_t)k * A * 4 * sizeof(float));
+        float *deltas = (float *)malloc((size_t)k * A * 4 * sizeof(float));
+        float *boxes = (float *)malloc((size_t)k * A * 4 * sizeof(float));
+        float *ldel = (float *)malloc((size_t)k * A * 10 * sizeof(float));
+        float *lpred = (float *)malloc((size_t)k * A * 10 * sizeof(float));
+        rfd_oracle_anchor_plane(fh, fw, s, base + l * 8, A, plane); /* :329 */
+        for (int h = 0; h < fh; ++h)
+            for (int w = 0; w < fw; ++w)
+                for (int a = 0; a < A; ++a) {
+                    int r = (h * fw + w) * A + a; /* NHWC flatten, :336-364 */
+                    for (int c = 0; c < 4; ++c)
+                        deltas[r * 4 + c] = bbx[((size_t)(4 * a + c) * fh + h) * fw + w] * 1.0f; /* bbox_stds :366-371 */
+                    for (int c = 0; c < 10; ++c)
+                        ldel[r * 10 + c] = lmd[((size_t)(10 * a + c) * fh + h) * fw + w] * 1.0f; /* landmark_std :398 */
+                }
+        rfd_oracle_bbox_pred(plane, deltas, k * A, boxes);      /* :372 */
+        rfd_oracle_clip_boxes(boxes, k * A, net_h, net_w);      /* :373 */
+        rfd_oracle_landmark_pred(plane, ldel, k * A, lpred);    /* :399 */
+        for (int h = 0; h < fh; ++h)
+            for (int w = 0; w < fw; ++w)
+                for (int a = 0; a < A; ++a) {
+                    int r = (h * fw + w) * A + a;
+                    float sc = cls[((size_t)(A + a) * fh + h) * fw + w]; /* :322 fg = channel A+a */
+                    if (sc >= conf_thr) {                                /* :375 */
+                        memcpy(props + 4 * n, boxes + 4 * r, 4 * sizeof(float));
+                        memcpy(lmks + 10 * n, lpred + 10 * r, 10 * sizeof(float));
+                        scores[n] = sc;
+                        gids[n] = goff + r;
+                        ++n;
+                    }
+                }
+        goff += k * A;
+        free(plane); free(deltas); free(boxes); free(ldel); free(lpred);
+    }
+    if (n_candidates) *n_candidates = n;
+
+    int K = 0;
+    if (n > 0) { /* :413-419 empty early-out otherwise */
+        int *order = (int *)malloc((size_t)n * sizeof(int));
+        rfd_oracle_argsort_desc(scores, n, order); /* :423 */
+        float *pre = (float *)malloc((size_t)n * 5 * sizeof(float));
+        for (int i = 0; i < n; ++i) { /* :424-430 */
+            memcpy(pre + 5 * i, props + 4 * order[i], 4 * sizeof(float));
+            pre[5 * i + 4] = scores[order[i]];
+        }
+        int *keep = (int *)malloc((size_t)n * sizeof(int));
+        K = rfd_oracle_nms(pre, n, iou_thr, keep); /* :431 */
+        for (int t = 0; t < K && t < cap; ++t) {   /* :433-464 */
+            int i = keep[t], src = order[i];
+            for (int c = 0; c < 4; ++c)
+                det[5 * t + c] = det_scale > 0.0f ? pre[5 * i + c] / det_scale : pre[5 * i + c]; /* :477-481 */
+            det[5 * t + 4] = pre[5 * i + 4];
+            for (int c = 0; c < 10; ++c)
+                lmk[10 * t + c] = det_scale > 0.0f ? lmks[10 * src + c] / det_scale : lmks[10 * src + c]; /* :483 */
+            if (gidx) gidx[t] = gids[src];
+        }
+        free(order); free(pre); free(keep);
+    }
+    free(props); free(scores); free(lmks); free(gids);
+    return K;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * _preprocess: face_detection.rs:131-198 (geometry) + OpenCV resize INTER_LINEAR 8UC3 (:156)
+ * ------------------------------------------------------------------------------------------ */
+
+/* face_detection.rs:140-153. image_size = (w, h). */
+RFD_API void rfd_oracle_geometry(int img_h, int img_w, int size_w, int size_h, int *new_w,
+                                 int *new_h, float *det_scale)
+{
+    float im_ratio = (float)img_h / (float)img_w;
+    float model_ratio = (float)size_h / (float)size_w;
+    if (im_ratio > model_ratio) {
+        *new_h = size_h;
+        *new_w = (int)((float)*new_h / im_ratio);
+    } else {
+        *new_w = size_w;
+        *new_h = (int)((float)*new_w * im_ratio);
+    }
+    *det_scale = (float)*new_h / (float)img_h;
+}
+
+static short sat_short_round(float v)
+{
+    /* cv::saturate_cast<short>(float) = saturate(cvRound(v)); cvRound rounds half to even */
+    long r = lrintf(v);
+    if (r > 32767) r = 32767;
+    if (r < -32768) r = -32768;
+    return (short)r;
+}
+
+/*
+ * cv::resize(src, dst, Size(dw,dh), 0, 0, INTER_LINEAR) for CV_8UC3 (third-party; restated from
+ * OpenCV 4.x imgproc/resize.cpp; unpinned).  Coefficients: fx = (float)((dx+0.5)*scale_x-0.5),
+ * scale_x = 1/((double)dw/sw); 11-bit fixed point (INTER_RESIZE_COEF_SCALE = 2048);
+ * horizontal pass in int, vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+ * When both scale factors are exactly 2 OpenCV switches INTER_LINEAR to INTER_AREA whose fast
+ * 2x2 path is (a+b+c+d+2)>>2.
+ */
+RFD_API void rfd_oracle_resize_linear_u8c3(const uint8_t *src, int sh, int sw, ptrdiff_t sstride,
+                                           uint8_t *dst, int dh, int dw, ptrdiff_t dstride)
+{
+    const int cn = 3;
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
+    int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y); /* saturate_cast<int> */
+    int is_area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 &&
+                       fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+        for (int dy = 0; dy < dh; ++dy) {
+            const uint8_t *s0 = src + (ptrdiff_t)(2 * dy) * sstride;
+            const uint8_t *s1 = s0 + sstride;
+            uint8_t *d = dst + (ptrdiff_t)dy * dstride;
+            for (int dx = 0; dx < dw; ++dx)
+                for (int c = 0; c < cn; ++c) {
+                    int i = 2 * dx * cn + c;
+                    d[dx * cn + c] = (uint8_t)((s0[i] + s0[i + cn] + s1[i] + s1[i + cn] + 2) >> 2);
+                }
+        }
+        return;
+    }
+    int *xofs = (int *)malloc((size_t)dw * sizeof(int));
+    short *ialpha = (short *)malloc((size_t)dw * 2 * sizeof(short));
+    int *rows0 = (int *)malloc((size_t)dw * cn * sizeof(int));
+    int *rows1 = (int *)malloc((size_t)dw * cn * sizeof(int));
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.0f; sx = 0; }
+        if (sx >= sw - 1) { fx = 0.0f; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx + 0] = sat_short_round((1.0f - fx) * 2048.0f);
+        ialpha[2 * dx + 1] = sat_short_round(fx * 2048.0f);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        short b0 = sat_short_round((1.0f - fy) * 2048.0f);
+        short b1 = sat_short_round(fy * 2048.0f);
+        int sy0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const uint8_t *S0 = src + (ptrdiff_t)sy0 * sstride, *S1 = src + (ptrdiff_t)sy1 * sstride;
+        for (int dx = 0; dx < dw; ++dx) {
+            int sx = xofs[dx];
+            int sx1 = sx + 1 < sw ? sx + 1 : sw - 1; /* a1 == 0 whenever sx is clamped */
+            int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            for (int c = 0; c < cn; ++c) {
+                rows0[dx * cn + c] = S0[sx * cn + c] * a0 + S0[sx1 * cn + c] * a1;
+                rows1[dx * cn + c] = S1[sx * cn + c] * a0 + S1[sx1 * cn + c] * a1;
+            }
+        }
+        uint8_t *d = dst + (ptrdiff_t)dy * dstride;
+        for (int x = 0; x < dw * cn; ++x)
+            d[x] = (uint8_t)((((b0 * (rows0[x] >> 4)) >> 16) + ((b1 * (rows1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(ialpha); free(rows0); free(rows1);
+}
+
+/*
+ * _preprocess (face_detection.rs:131-198) + tensorise loop (:220-232).
+ * src: HxWx3 u8 BGR with row stride sstride.  det_img (optional): size_h x size_w x 3 u8.
+ * tensor (optional): [3][size_h][size_w] f32, channel order R,G,B, raw 0..255 values
+ * (pixel_scale 1, mean 0, std 1, :105-107, :227).  Returns det_scale.
+ */
+RFD_API float rfd_oracle_preprocess(const uint8_t *src, int img_h, int img_w, ptrdiff_t sstride,
+                                    int size_w, int size_h, uint8_t *det_img, float *tensor)
+{
+    int new_w, new_h;
+    float det_scale;
+    rfd_oracle_geometry(img_h, img_w, size_w, size_h, &new_w, &new_h, &det_scale);
+    uint8_t *canvas = det_img ? det_img : (uint8_t *)malloc((size_t)size_h * size_w * 3);
+    memset(canvas, 0, (size_t)size_h * size_w * 3); /* :169 zero canvas */
+    if (new_w > 0 && new_h > 0)
+        rfd_oracle_resize_linear_u8c3(src, img_h, img_w, sstride, canvas, new_h, new_w,
+                                      (ptrdiff_t)size_w * 3); /* :156 + paste at (0,0) :176-183 */
+    if (tensor) {
+        for (int i = 0; i < 3; ++i) /* :223-230 */
+            for (int y = 0; y < size_h; ++y)
+                for (int x = 0; x < size_w; ++x) {
+                    uint8_t p = canvas[((size_t)y * size_w + x) * 3 + (2 - i)];
+                    tensor[((size_t)i * size_h + y) * size_w + x] = ((float)p / 1.0f - 0.0f) / 1.0f;
+                }
+    }
+    if (!det_img) free(canvas);
+    return det_scale;
+}

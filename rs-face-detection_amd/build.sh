@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds librfd_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function"
+OBJ="$HERE/build"
+mkdir -p "$OBJ"
+pids=()
+for f in kernels_pre kernels_post kernels_conv network detector; do
+  src="$HERE/csrc/$f.hip"
+  if [ ! -f "$OBJ/$f.o" ] || [ "$src" -nt "$OBJ/$f.o" ] || [ -n "$(find "$HERE/csrc" "$HERE/../include" -name '*.h' -newer "$OBJ/$f.o")" ]; then
+    $HIPCC $FLAGS -c "$src" -o "$OBJ/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/librfd_hip.so" "$OBJ"/kernels_pre.o "$OBJ"/kernels_post.o "$OBJ"/kernels_conv.o "$OBJ"/network.o "$OBJ"/detector.o
+echo "built $HERE/librfd_hip.so"

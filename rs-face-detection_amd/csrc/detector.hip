@@ -1,0 +1,765 @@
+// detector.hip -- host side of the detection stage: the C++ mirror of the reference's
+// `RetinaFaceDetection` (src/pipeline/module/face_detection.rs:19-513) driving the HIP kernels, and
+// the C ABI of include/rfd.h on top of it.  (The reference's host language, Rust, has no toolchain
+// in this image; INTEGRATION.md shows the `extern "C"` facade that keeps its `call` signature.)
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "network.h"
+
+namespace rfd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+// ---- anchors: generate_anchors_fpn2 with the production config (face_detection.rs:55-98,
+//      generate_anchors.rs:20-39, 61-93, 116-157); f32 arithmetic in the reference's order ----
+static void make_base_anchors(float out[kNumLevels][kA][4])
+{
+    static const float scales[kNumLevels][kA] = {{32.f, 16.f}, {8.f, 4.f}, {2.f, 1.f}};
+    const int base_size = 16;
+    const float ratio = 1.0f;
+    for (int l = 0; l < kNumLevels; ++l) {
+        // base anchor [0,0,15,15] -> (w,h,ctr)
+        const float b0 = 1.0f - 1.0f, b2 = (float)base_size - 1.0f;
+        float w = b2 - b0 + 1.0f, h = b2 - b0 + 1.0f;
+        float xc = b0 + 0.5f * (w - 1.0f), yc = b0 + 0.5f * (h - 1.0f);
+        // _ratio_enum
+        const float ws = roundf(sqrtf(w * h / ratio)), hs = ws * ratio;
+        const float r0 = xc - 0.5f * (ws - 1.0f), r1 = yc - 0.5f * (hs - 1.0f);
+        const float r2 = xc + 0.5f * (ws - 1.0f), r3 = yc + 0.5f * (hs - 1.0f);
+        // _scale_enum
+        w = r2 - r0 + 1.0f; h = r3 - r1 + 1.0f;
+        xc = r0 + 0.5f * (w - 1.0f); yc = r1 + 0.5f * (h - 1.0f);
+        for (int a = 0; a < kA; ++a) {
+            const float sw = w * scales[l][a], sh = h * scales[l][a];
+            out[l][a][0] = xc - 0.5f * (sw - 1.0f);
+            out[l][a][1] = yc - 0.5f * (sh - 1.0f);
+            out[l][a][2] = xc + 0.5f * (sw - 1.0f);
+            out[l][a][3] = yc + 0.5f * (sh - 1.0f);
+        }
+    }
+}
+
+// ---- _preprocess geometry (face_detection.rs:140-153) + cv::resize's scale bookkeeping ----
+static void letterbox(int img_h, int img_w, int size_w, int size_h, PreImage *pi, float *det_scale)
+{
+    const float im_ratio = (float)img_h / (float)img_w;
+    const float model_ratio = (float)size_h / (float)size_w;
+    int new_w, new_h;
+    if (im_ratio > model_ratio) {
+        new_h = size_h;
+        new_w = (int)((float)new_h / im_ratio);
+    } else {
+        new_w = size_w;
+        new_h = (int)((float)new_w * im_ratio);
+    }
+    *det_scale = (float)new_h / (float)img_h;
+    pi->h = img_h; pi->w = img_w; pi->new_w = new_w; pi->new_h = new_h; pi->pad = 0;
+    pi->scale_x = pi->scale_y = 1.0;
+    pi->area_fast = 0;
+    if (new_w > 0 && new_h > 0) {
+        const double inv_x = (double)new_w / img_w, inv_y = (double)new_h / img_h;
+        pi->scale_x = 1.0 / inv_x;
+        pi->scale_y = 1.0 / inv_y;
+        const int ix = (int)lrint(pi->scale_x), iy = (int)lrint(pi->scale_y);
+        pi->area_fast = fabs(pi->scale_x - ix) < 2.220446049250313e-16 &&
+                        fabs(pi->scale_y - iy) < 2.220446049250313e-16 && ix == 2 && iy == 2;
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return RFD_OK;
+        if (p) RFD_HIP(hipFree(p));
+        p = nullptr; cap = 0;
+        RFD_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return RFD_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace rfd
+
+using namespace rfd;
+
+// The context = the reference's `RetinaFaceDetection` struct (face_detection.rs:19-38) minus the
+// Triton client/model config, plus device state.
+struct rfd_ctx {
+    rfd_config cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[10] = {};
+    float base_anchor[kNumLevels][kA][4];
+    int fh[kNumLevels], fw[kNumLevels], level_off[kNumLevels], total_anchors = 0;
+    Network net;
+    bool net_created = false;
+    // device state sized for max_batch_size
+    DevBuf staging, imgs, in4, rows, keys, sorted_keys, sorted_boxes, count, det_scale;
+    DevBuf out_boxes, out_lmk, out_count, out_total, out_gidx;
+    DevBuf scratch[12];
+    // pinned host ring for per-call descriptors, so enqueueing never blocks on the previous call
+    static constexpr int kRing = 4;
+    PreImage *pin_imgs[kRing] = {};
+    float *pin_scales[kRing] = {};
+    hipEvent_t pin_done[kRing] = {};
+    int pin_next = 0;
+    rfd_stats stats;
+    float conv_ms = 0.f;
+    double conv_flops = 0.0;
+    int conv_launches = 0;
+
+    int ensure_network()
+    {
+        if (net_created) return RFD_OK;
+        RFD_TRY(net.create(cfg.backbone, cfg.image_w, cfg.image_h, cfg.max_batch_size));
+        net_created = true;
+        return RFD_OK;
+    }
+};
+
+namespace {
+
+int ctx_alloc(rfd_ctx *c)
+{
+    const size_t B = (size_t)c->cfg.max_batch_size, NA = (size_t)c->total_anchors, MD = (size_t)c->cfg.max_det;
+    RFD_TRY(c->imgs.reserve(B * sizeof(PreImage)));
+    RFD_TRY(c->rows.reserve(B * NA * kDetRow * sizeof(float)));
+    RFD_TRY(c->keys.reserve(B * NA * sizeof(uint64_t)));
+    RFD_TRY(c->sorted_keys.reserve(B * NA * sizeof(uint64_t)));
+    RFD_TRY(c->sorted_boxes.reserve(B * NA * sizeof(float4)));
+    RFD_TRY(c->count.reserve(B * sizeof(int)));
+    RFD_TRY(c->det_scale.reserve(B * sizeof(float)));
+    RFD_TRY(c->out_boxes.reserve(B * MD * 5 * sizeof(float)));
+    RFD_TRY(c->out_lmk.reserve(B * MD * 10 * sizeof(float)));
+    RFD_TRY(c->out_count.reserve(B * sizeof(int)));
+    RFD_TRY(c->out_total.reserve(B * sizeof(int)));
+    RFD_TRY(c->out_gidx.reserve(B * MD * sizeof(int)));
+    return RFD_OK;
+}
+
+int check_images(const rfd_ctx *c, const rfd_image *imgs, int n)
+{
+    RFD_CHECK_ARG(imgs != nullptr, "imgs is null");
+    if (n < 1 || n > c->cfg.max_batch_size) {
+        set_error("batch of %d frames exceeds max_batch_size %d", n, c->cfg.max_batch_size);
+        return RFD_ERR_CAPACITY;
+    }
+    for (int i = 0; i < n; ++i) {
+        RFD_CHECK_ARG(imgs[i].data != nullptr, "frame data is null");
+        RFD_CHECK_ARG(imgs[i].height > 0 && imgs[i].width > 0, "frame has a non-positive size");
+        RFD_CHECK_ARG(imgs[i].stride >= (ptrdiff_t)imgs[i].width * 3, "frame stride < width*3 (frames must be 3-channel 8-bit)");
+    }
+    return RFD_OK;
+}
+
+// Stage the frames (host or device resident) and their letterbox geometry on the device.
+int stage_frames(rfd_ctx *c, const rfd_image *imgs, int n, bool frames_on_device, std::vector<float> &scales)
+{
+    const int slot = c->pin_next;
+    c->pin_next = (c->pin_next + 1) % rfd_ctx::kRing;
+    RFD_HIP(hipEventSynchronize(c->pin_done[slot])); // the copy that last used this slot has run
+    PreImage *pis = c->pin_imgs[slot];
+    scales.resize(n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)imgs[i].height * imgs[i].width * 3;
+    if (!frames_on_device) RFD_TRY(c->staging.reserve(total));
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        letterbox(imgs[i].height, imgs[i].width, c->cfg.image_w, c->cfg.image_h, &pis[i], &scales[i]);
+        if (pis[i].new_w <= 0 || pis[i].new_h <= 0) { // the reference's cv::resize errors out on an empty dsize (face_detection.rs:156-159)
+            set_error("invalid argument: frame %d (%dx%d) letterboxes to an empty %dx%d image", i, imgs[i].width,
+                      imgs[i].height, pis[i].new_w, pis[i].new_h);
+            return RFD_ERR_INVALID_ARG;
+        }
+        if (frames_on_device) {
+            pis[i].src = imgs[i].data;
+            pis[i].stride = (long long)imgs[i].stride;
+        } else {
+            uint8_t *dst = (uint8_t *)c->staging.p + off;
+            const size_t row = (size_t)imgs[i].width * 3;
+            RFD_HIP(hipMemcpy2DAsync(dst, row, imgs[i].data, (size_t)imgs[i].stride, row, imgs[i].height,
+                                     hipMemcpyHostToDevice, c->stream));
+            pis[i].src = dst;
+            pis[i].stride = (long long)row;
+            off += row * imgs[i].height;
+        }
+    }
+    memcpy(c->pin_scales[slot], scales.data(), n * sizeof(float));
+    RFD_HIP(hipMemcpyAsync(c->imgs.p, pis, n * sizeof(PreImage), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipMemcpyAsync(c->det_scale.p, c->pin_scales[slot], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipEventRecord(c->pin_done[slot], c->stream));
+    return RFD_OK;
+}
+
+void fill_decode_params(const rfd_ctx *c, DecodeParams &p)
+{
+    memset(&p, 0, sizeof p);
+    for (int l = 0; l < kNumLevels; ++l) {
+        p.fh[l] = c->fh[l]; p.fw[l] = c->fw[l]; p.stride[l] = kStrides[l]; p.level_off[l] = c->level_off[l];
+    }
+    memcpy(p.base_anchor, c->base_anchor, sizeof p.base_anchor);
+    p.total_anchors = c->total_anchors;
+    p.net_h = c->cfg.image_h; p.net_w = c->cfg.image_w;
+    p.conf_thr = c->cfg.confidence_threshold;
+    p.rows = (float *)c->rows.p;
+    p.keys = (uint64_t *)c->keys.p;
+    p.count = (int *)c->count.p;
+}
+
+// decode -> sort -> NMS on device-resident heads; outputs to device slabs `o*`.
+int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, float *olmk, int *ocount,
+                 int *ototal, int *ogidx)
+{
+    RFD_HIP(hipMemsetAsync(c->count.p, 0, n * sizeof(int), c->stream));
+    RFD_TRY(launch_decode(dp, n, nchw, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[4], c->stream));
+    RFD_TRY(launch_sort((const uint64_t *)c->keys.p, (const int *)c->count.p, (const float *)c->rows.p,
+                        (uint64_t *)c->sorted_keys.p, (float4 *)c->sorted_boxes.p, c->total_anchors, n, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[5], c->stream));
+    NmsParams np;
+    memset(&np, 0, sizeof np);
+    np.sorted_keys = (const uint64_t *)c->sorted_keys.p;
+    np.sorted_boxes = (const float4 *)c->sorted_boxes.p;
+    np.rows = (const float *)c->rows.p;
+    np.count = (const int *)c->count.p;
+    np.det_scale = (const float *)c->det_scale.p;
+    np.presorted_n = -1;
+    np.total_anchors = c->total_anchors;
+    np.max_det = c->cfg.max_det;
+    np.iou_thr = c->cfg.iou_threshold;
+    np.out_boxes = oboxes; np.out_lmk = olmk; np.out_count = ocount; np.out_total = ototal; np.out_gidx = ogidx;
+    RFD_TRY(launch_nms(np, n, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[6], c->stream));
+    return RFD_OK;
+}
+
+int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
+{
+    float ms;
+    memset(&c->stats, 0, sizeof c->stats);
+    auto el = [&](int a, int b) { return hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess ? ms : 0.f; };
+    if (have_pre) { c->stats.ms_h2d = el(0, 1); c->stats.ms_preprocess = el(1, 2); }
+    if (have_net) c->stats.ms_network = el(2, 3);
+    c->stats.ms_decode = el(3, 4);
+    c->stats.ms_sort = el(4, 5);
+    c->stats.ms_nms = el(5, 6);
+    c->stats.ms_d2h = el(6, 7);
+    c->stats.ms_total = el(have_pre ? 0 : (have_net ? 2 : 3), 7);
+    std::vector<int> cnt(n), tot(n);
+    RFD_HIP(hipMemcpy(cnt.data(), c->count.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) c->stats.candidates += cnt[i];
+    if (c->net_created && c->net.profiling) {
+        RFD_TRY(c->net.collect_profile());
+        c->conv_ms = 0.f; c->conv_flops = 0.0; c->conv_launches = 0;
+        for (size_t i = 0; i < c->net.g.ops.size(); ++i)
+            if (c->net.g.ops[i].kind == OP_CONV) {
+                c->conv_ms += c->net.op_ms[i];
+                c->conv_flops += 2.0 * c->net.g.layer_macs((int)i) * n;
+                ++c->conv_launches;
+            }
+    }
+    return RFD_OK;
+}
+
+int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on_device, int async)
+{
+    RFD_CHECK_ARG(c != nullptr, "ctx is null");
+    RFD_CHECK_ARG(out && out->boxes && out->landmarks && out->count, "output buffers are null");
+    RFD_TRY(check_images(c, imgs, n));
+    RFD_TRY(c->ensure_network());
+    if (!c->net.weights_ready) { set_error("network weights are not initialised"); return RFD_ERR_STATE; }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    std::vector<float> scales;
+    RFD_HIP(hipEventRecord(c->ev[0], c->stream));
+    RFD_TRY(stage_frames(c, imgs, n, on_device, scales));
+    RFD_HIP(hipEventRecord(c->ev[1], c->stream));
+    PreParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.imgs = (const PreImage *)c->imgs.p;
+    pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
+    pp.out_nhwc4 = (bf16_t *)c->net.tensor_ptr(c->net.g.input);
+    RFD_TRY(launch_preprocess(pp, n, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[2], c->stream));
+    RFD_TRY(c->net.run(n, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[3], c->stream));
+    DecodeParams dp;
+    fill_decode_params(c, dp);
+    for (int l = 0; l < kNumLevels; ++l) dp.cls[l] = (const float *)c->net.tensor_ptr(c->net.g.heads[l]);
+    float *ob = on_device ? out->boxes : (float *)c->out_boxes.p;
+    float *ol = on_device ? out->landmarks : (float *)c->out_lmk.p;
+    int *oc = on_device ? out->count : (int *)c->out_count.p;
+    int *ot = on_device ? out->total : (int *)c->out_total.p;
+    RFD_TRY(post_network(c, dp, false, n, ob, ol, oc, ot, nullptr));
+    if (!on_device) {
+        const size_t MD = (size_t)c->cfg.max_det;
+        RFD_HIP(hipMemcpyAsync(out->boxes, ob, n * MD * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RFD_HIP(hipMemcpyAsync(out->landmarks, ol, n * MD * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RFD_HIP(hipMemcpyAsync(out->count, oc, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (out->total) RFD_HIP(hipMemcpyAsync(out->total, ot, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    RFD_HIP(hipEventRecord(c->ev[7], c->stream));
+    if (async && on_device) return RFD_OK;
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_TRY(finish_stats(c, n, true, true));
+    if (!on_device)
+        for (int i = 0; i < n; ++i) c->stats.detections += out->total ? out->total[i] : out->count[i];
+    return RFD_OK;
+}
+
+std::mutex g_nms_mu;
+rfd_ctx *g_nms_ctx[16] = {};
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+void rfd_config_default(rfd_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->image_w = 640;                 // config.rs:26
+    cfg->image_h = 640;
+    cfg->max_batch_size = 1;            // config.rs:28
+    cfg->confidence_threshold = 0.7f;   // config.rs:29
+    cfg->iou_threshold = 0.45f;         // config.rs:30
+    cfg->device_id = 0;
+    cfg->max_det = 1024;
+    cfg->max_src_w = 3840;
+    cfg->max_src_h = 2160;
+    cfg->backbone = RFD_BACKBONE_R50;
+}
+
+int rfd_version(void) { return RFD_VERSION; }
+const char *rfd_last_error(void) { return get_error(); }
+
+int rfd_create(const rfd_config *cfg, rfd_ctx **out)
+{
+    RFD_CHECK_ARG(cfg && out, "cfg/out is null");
+    *out = nullptr;
+    RFD_CHECK_ARG(cfg->image_w > 0 && cfg->image_h > 0 && cfg->image_w % 32 == 0 && cfg->image_h % 32 == 0,
+                  "image_size must be positive multiples of 32");
+    RFD_CHECK_ARG(cfg->max_batch_size >= 1, "max_batch_size < 1");
+    RFD_CHECK_ARG(cfg->max_det >= 1, "max_det < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device is available: librfd_hip has no CPU fallback");
+        return RFD_ERR_NO_DEVICE;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) {
+        set_error("device_id %d out of range (%d devices)", cfg->device_id, ndev);
+        return RFD_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(cfg->device_id) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", cfg->device_id);
+        return RFD_ERR_NO_DEVICE;
+    }
+    rfd_ctx *c = new rfd_ctx();
+    c->cfg = *cfg;
+    make_base_anchors(c->base_anchor);
+    int off = 0;
+    for (int l = 0; l < kNumLevels; ++l) {
+        c->fh[l] = cfg->image_h / kStrides[l];
+        c->fw[l] = cfg->image_w / kStrides[l];
+        c->level_off[l] = off;
+        off += c->fh[l] * c->fw[l] * kA;
+    }
+    c->total_anchors = off;
+    memset(&c->stats, 0, sizeof c->stats);
+    int st = RFD_OK;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) st = RFD_ERR_HIP;
+    for (int i = 0; i < 10 && st == RFD_OK; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) st = RFD_ERR_HIP;
+    for (int i = 0; i < rfd_ctx::kRing && st == RFD_OK; ++i) {
+        if (hipHostMalloc((void **)&c->pin_imgs[i], cfg->max_batch_size * sizeof(PreImage)) != hipSuccess ||
+            hipHostMalloc((void **)&c->pin_scales[i], cfg->max_batch_size * sizeof(float)) != hipSuccess ||
+            hipEventCreate(&c->pin_done[i]) != hipSuccess)
+            st = RFD_ERR_HIP;
+    }
+    if (st == RFD_OK) st = ctx_alloc(c);
+    if (st != RFD_OK) {
+        if (st == RFD_ERR_HIP && !*get_error()) set_error("HIP stream/event creation failed");
+        rfd_destroy(c);
+        return st;
+    }
+    *out = c;
+    return RFD_OK;
+}
+
+void rfd_destroy(rfd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->net_created) c->net.destroy();
+    DevBuf *bufs[] = {&c->staging, &c->imgs, &c->in4, &c->rows, &c->keys, &c->sorted_keys, &c->sorted_boxes,
+                      &c->count, &c->det_scale, &c->out_boxes, &c->out_lmk, &c->out_count, &c->out_total,
+                      &c->out_gidx};
+    for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : c->scratch) b.release();
+    for (int i = 0; i < 10; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < rfd_ctx::kRing; ++i) {
+        if (c->pin_imgs[i]) (void)hipHostFree(c->pin_imgs[i]);
+        if (c->pin_scales[i]) (void)hipHostFree(c->pin_scales[i]);
+        if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rfd_get_config(const rfd_ctx *c, rfd_config *cfg)
+{
+    RFD_CHECK_ARG(c && cfg, "null argument");
+    *cfg = c->cfg;
+    return RFD_OK;
+}
+
+int rfd_get_stats(rfd_ctx *c, rfd_stats *stats)
+{
+    RFD_CHECK_ARG(c && stats, "null argument");
+    *stats = c->stats;
+    return RFD_OK;
+}
+
+int rfd_set_thresholds(rfd_ctx *c, float confidence_threshold, float iou_threshold)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    c->cfg.confidence_threshold = confidence_threshold;
+    c->cfg.iou_threshold = iou_threshold;
+    return RFD_OK;
+}
+
+int rfd_set_profiling(rfd_ctx *c, int enable)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_TRY(c->ensure_network());
+    c->net.profiling = enable != 0;
+    return RFD_OK;
+}
+
+int rfd_get_conv_profile(rfd_ctx *c, float *ms_conv, double *flops_conv, int *launches)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    if (ms_conv) *ms_conv = c->conv_ms;
+    if (flops_conv) *flops_conv = c->conv_flops;
+    if (launches) *launches = c->conv_launches;
+    return RFD_OK;
+}
+
+int rfd_get_op_profile(rfd_ctx *c, float *ms, int cap)
+{
+    RFD_CHECK_ARG(c && ms, "null argument");
+    if (!c->net_created) { set_error("no network"); return RFD_ERR_STATE; }
+    const int n = (int)c->net.op_ms.size();
+    for (int i = 0; i < n && i < cap; ++i) ms[i] = c->net.op_ms[i];
+    return n;
+}
+
+// ---- graph description (host only; usable without a GPU) ----
+int rfd_graph_create(int backbone, int image_w, int image_h, rfd_graph **out)
+{
+    RFD_CHECK_ARG(out, "out is null");
+    Graph *g = new Graph();
+    const int st = g->build(backbone, image_w, image_h);
+    if (st != RFD_OK) { delete g; *out = nullptr; return st; }
+    *out = reinterpret_cast<rfd_graph *>(g);
+    return RFD_OK;
+}
+void rfd_graph_destroy(rfd_graph *g) { delete reinterpret_cast<Graph *>(g); }
+int rfd_graph_counts(const rfd_graph *gg, int *layers, int *ops, int *tensors, int *buffers)
+{
+    RFD_CHECK_ARG(gg, "graph is null");
+    const Graph *g = reinterpret_cast<const Graph *>(gg);
+    if (layers) *layers = (int)g->layers.size();
+    if (ops) *ops = (int)g->ops.size();
+    if (tensors) *tensors = (int)g->tensors.size();
+    if (buffers) *buffers = (int)g->buffer_bytes_per_image.size();
+    return RFD_OK;
+}
+int rfd_graph_layer(const rfd_graph *gg, int idx, rfd_layer_desc *d)
+{
+    RFD_CHECK_ARG(gg && d, "null argument");
+    const Graph *g = reinterpret_cast<const Graph *>(gg);
+    RFD_CHECK_ARG(idx >= 0 && idx < (int)g->layers.size(), "layer index out of range");
+    const Layer &L = g->layers[idx];
+    memset(d, 0, sizeof *d);
+    snprintf(d->name, sizeof d->name, "%s", L.name.c_str());
+    d->cin = L.cin; d->cout = L.cout; d->kh = L.kh; d->kw = L.kw; d->stride = L.stride; d->pad = L.pad;
+    d->has_affine = L.has_affine;
+    return RFD_OK;
+}
+int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
+{
+    RFD_CHECK_ARG(gg && d, "null argument");
+    const Graph *g = reinterpret_cast<const Graph *>(gg);
+    RFD_CHECK_ARG(idx >= 0 && idx < (int)g->ops.size(), "op index out of range");
+    const Op &o = g->ops[idx];
+    memset(d, 0, sizeof *d);
+    d->kind = o.kind; d->layer = o.layer; d->in = o.in; d->out = o.out; d->out2 = o.out2; d->outf = o.outf;
+    d->res = o.res; d->relu = o.relu; d->res_up2 = o.res_up2; d->res_post = o.res_post;
+    d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
+    d->macs = g->layer_macs(idx);
+    return RFD_OK;
+}
+int rfd_graph_tensor(const rfd_graph *gg, int idx, rfd_tensor_desc *d)
+{
+    RFD_CHECK_ARG(gg && d, "null argument");
+    const Graph *g = reinterpret_cast<const Graph *>(gg);
+    RFD_CHECK_ARG(idx >= 0 && idx < (int)g->tensors.size(), "tensor index out of range");
+    const TensorDesc &t = g->tensors[idx];
+    memset(d, 0, sizeof *d);
+    d->channels = t.C; d->height = t.H; d->width = t.W; d->is_f32 = t.is_f32; d->buffer = t.buffer;
+    d->is_input = idx == g->input;
+    for (int l = 0; l < 3; ++l)
+        if (g->heads[l] == idx) d->head_level = l + 1;
+    return RFD_OK;
+}
+double rfd_graph_macs(const rfd_graph *gg)
+{
+    return gg ? reinterpret_cast<const Graph *>(gg)->macs_per_image() : 0.0;
+}
+double rfd_graph_workspace_bytes(const rfd_graph *gg)
+{
+    if (!gg) return 0.0;
+    double s = 0;
+    for (size_t b : reinterpret_cast<const Graph *>(gg)->buffer_bytes_per_image) s += (double)b;
+    return s;
+}
+
+// ---- test hooks: raw tensor access and partial execution of the network ----
+int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
+{
+    RFD_CHECK_ARG(c && host, "null argument");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    RFD_CHECK_ARG(tensor_id >= 0 && tensor_id < (int)c->net.g.tensors.size(), "tensor id out of range");
+    RFD_CHECK_ARG(n >= 1 && n <= c->cfg.max_batch_size, "batch out of range");
+    const size_t bytes = c->net.g.tensors[tensor_id].bytes_per_image() * (size_t)n;
+    if (write) RFD_HIP(hipMemcpyAsync(c->net.tensor_ptr(tensor_id), host, bytes, hipMemcpyHostToDevice, c->stream));
+    else RFD_HIP(hipMemcpyAsync(host, c->net.tensor_ptr(tensor_id), bytes, hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    RFD_TRY(c->net.run(n, c->stream, first_op, last_op));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    if (c->net.profiling) RFD_TRY(c->net.collect_profile());
+    return RFD_OK;
+}
+
+// ---- weights ----
+int rfd_init_synthetic_weights(rfd_ctx *c, uint64_t seed)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    return c->net.init_synthetic(seed, c->stream);
+}
+int rfd_num_layers(const rfd_ctx *c)
+{
+    if (!c || !c->net_created) return 0;
+    return (int)c->net.g.layers.size();
+}
+int rfd_get_layer_weights(rfd_ctx *c, int idx, float *weights, float *bias)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_TRY(c->ensure_network());
+    return c->net.get_layer(idx, weights, bias, c->stream);
+}
+int rfd_set_layer_weights(rfd_ctx *c, int idx, const float *weights, const float *bias)
+{
+    RFD_CHECK_ARG(c && weights, "null argument");
+    RFD_TRY(c->ensure_network());
+    RFD_TRY(c->net.set_layer(idx, weights, bias, c->stream));
+    c->net.weights_ready = true;
+    return RFD_OK;
+}
+int rfd_get_layer_affine(rfd_ctx *c, int idx, float *scale, float *shift)
+{
+    RFD_CHECK_ARG(c && scale && shift, "null argument");
+    RFD_TRY(c->ensure_network());
+    return c->net.get_affine(idx, scale, shift, c->stream);
+}
+int rfd_set_layer_affine(rfd_ctx *c, int idx, const float *scale, const float *shift)
+{
+    RFD_CHECK_ARG(c && scale && shift, "null argument");
+    RFD_TRY(c->ensure_network());
+    return c->net.set_affine(idx, scale, shift, c->stream);
+}
+
+// ---- hot path ----
+int rfd_detect_batch(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
+{
+    return detect_impl(c, imgs, n, out, false, 0);
+}
+int rfd_detect_batch_device(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, int async)
+{
+    RFD_CHECK_ARG(out && out->total, "out->total must be a device buffer for the device entry point");
+    return detect_impl(c, imgs, n, out, true, async);
+}
+int rfd_sync(rfd_ctx *c)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+
+// ---- stage-level entry points ----
+int rfd_preprocess(rfd_ctx *c, const rfd_image *imgs, int n, uint8_t *det_img, float *tensor, float *det_scale)
+{
+    RFD_CHECK_ARG(c != nullptr, "ctx is null");
+    RFD_TRY(check_images(c, imgs, n));
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    std::vector<float> scales;
+    RFD_TRY(stage_frames(c, imgs, n, false, scales));
+    const size_t npix = (size_t)n * c->cfg.image_h * c->cfg.image_w;
+    PreParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.imgs = (const PreImage *)c->imgs.p;
+    pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
+    if (det_img) { RFD_TRY(c->scratch[0].reserve(npix * 3)); pp.out_det_img = (uint8_t *)c->scratch[0].p; }
+    if (tensor) { RFD_TRY(c->scratch[1].reserve(npix * 3 * sizeof(float))); pp.out_tensor = (float *)c->scratch[1].p; }
+    RFD_TRY(launch_preprocess(pp, n, c->stream));
+    if (det_img) RFD_HIP(hipMemcpyAsync(det_img, pp.out_det_img, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    if (tensor) RFD_HIP(hipMemcpyAsync(tensor, pp.out_tensor, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    if (det_scale) memcpy(det_scale, scales.data(), n * sizeof(float));
+    return RFD_OK;
+}
+
+int rfd_forward(rfd_ctx *c, const float *tensor, int n, float *const heads[9])
+{
+    RFD_CHECK_ARG(c && tensor && heads, "null argument");
+    for (int i = 0; i < 9; ++i) RFD_CHECK_ARG(heads[i] != nullptr, "head pointer is null");
+    if (n < 1 || n > c->cfg.max_batch_size) { set_error("batch %d exceeds max_batch_size %d", n, c->cfg.max_batch_size); return RFD_ERR_CAPACITY; }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    const size_t plane = (size_t)c->cfg.image_h * c->cfg.image_w;
+    RFD_TRY(c->scratch[1].reserve(n * plane * 3 * sizeof(float)));
+    RFD_HIP(hipMemcpyAsync(c->scratch[1].p, tensor, n * plane * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_TRY(launch_tensor_to_nhwc4((const float *)c->scratch[1].p, (bf16_t *)c->net.tensor_ptr(c->net.g.input), n,
+                                   c->cfg.image_h, c->cfg.image_w, c->stream));
+    RFD_TRY(c->net.run(n, c->stream));
+    for (int l = 0; l < kNumLevels; ++l) {
+        const size_t hw = (size_t)c->fh[l] * c->fw[l];
+        RFD_TRY(c->scratch[2].reserve(n * hw * 32 * sizeof(float)));
+        float *base = (float *)c->scratch[2].p;
+        float *cls = base, *bbox = base + n * hw * 4, *lmk = base + n * hw * 12;
+        RFD_TRY(launch_heads_to_nchw((const float *)c->net.tensor_ptr(c->net.g.heads[l]), cls, bbox, lmk, n,
+                                     c->fh[l], c->fw[l], c->stream));
+        RFD_HIP(hipMemcpyAsync(heads[3 * l + 0], cls, n * hw * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RFD_HIP(hipMemcpyAsync(heads[3 * l + 1], bbox, n * hw * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RFD_HIP(hipMemcpyAsync(heads[3 * l + 2], lmk, n * hw * 20 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RFD_HIP(hipStreamSynchronize(c->stream)); // scratch[2] is reused by the next level
+    }
+    if (c->net.profiling) RFD_TRY(c->net.collect_profile());
+    return RFD_OK;
+}
+
+int rfd_decode_nms(rfd_ctx *c, const float *const heads[9], int n, const float *det_scale, rfd_dets *out,
+                   int32_t *gidx)
+{
+    RFD_CHECK_ARG(c && heads && det_scale, "null argument");
+    RFD_CHECK_ARG(out && out->boxes && out->landmarks && out->count, "output buffers are null");
+    for (int i = 0; i < 9; ++i) RFD_CHECK_ARG(heads[i] != nullptr, "head pointer is null");
+    if (n < 1 || n > c->cfg.max_batch_size) { set_error("batch %d exceeds max_batch_size %d", n, c->cfg.max_batch_size); return RFD_ERR_CAPACITY; }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    static const int chans[3] = {2 * kA, 4 * kA, 10 * kA};
+    DecodeParams dp;
+    fill_decode_params(c, dp);
+    for (int l = 0; l < kNumLevels; ++l)
+        for (int k = 0; k < 3; ++k) {
+            const size_t bytes = (size_t)n * chans[k] * c->fh[l] * c->fw[l] * sizeof(float);
+            DevBuf &b = c->scratch[3 + 3 * l + k];
+            RFD_TRY(b.reserve(bytes));
+            RFD_HIP(hipMemcpyAsync(b.p, heads[3 * l + k], bytes, hipMemcpyHostToDevice, c->stream));
+            (k == 0 ? dp.cls[l] : k == 1 ? dp.bbox[l] : dp.lmk[l]) = (const float *)b.p;
+        }
+    RFD_HIP(hipMemcpyAsync(c->det_scale.p, det_scale, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[3], c->stream));
+    RFD_TRY(post_network(c, dp, true, n, (float *)c->out_boxes.p, (float *)c->out_lmk.p, (int *)c->out_count.p,
+                         (int *)c->out_total.p, gidx ? (int *)c->out_gidx.p : nullptr));
+    const size_t MD = (size_t)c->cfg.max_det;
+    RFD_HIP(hipMemcpyAsync(out->boxes, c->out_boxes.p, n * MD * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(out->landmarks, c->out_lmk.p, n * MD * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(out->count, c->out_count.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (out->total) RFD_HIP(hipMemcpyAsync(out->total, c->out_total.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (gidx) RFD_HIP(hipMemcpyAsync(gidx, c->out_gidx.p, n * MD * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipEventRecord(c->ev[7], c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_TRY(finish_stats(c, n, false, false));
+    for (int i = 0; i < n; ++i) c->stats.detections += out->total ? out->total[i] : out->count[i];
+    return RFD_OK;
+}
+
+int rfd_nms_sorted(rfd_ctx *c, int32_t *keep, int *num_out, const float *boxes, int boxes_num, int boxes_dim,
+                   float thresh)
+{
+    RFD_CHECK_ARG(c && keep && num_out && (boxes || boxes_num == 0), "null argument");
+    RFD_CHECK_ARG(boxes_num >= 0 && boxes_dim >= 4, "boxes_num < 0 or boxes_dim < 4");
+    *num_out = 0;
+    if (boxes_num == 0) return RFD_OK;
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    std::vector<float4> packed(boxes_num);
+    for (int i = 0; i < boxes_num; ++i) {
+        const float *b = boxes + (size_t)i * boxes_dim;
+        packed[i] = make_float4(b[0], b[1], b[2], b[3]);
+    }
+    RFD_TRY(c->scratch[0].reserve((size_t)boxes_num * sizeof(float4)));
+    RFD_TRY(c->scratch[1].reserve((size_t)boxes_num * sizeof(int) + 2 * sizeof(int)));
+    RFD_HIP(hipMemcpyAsync(c->scratch[0].p, packed.data(), boxes_num * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    NmsParams np;
+    memset(&np, 0, sizeof np);
+    np.sorted_boxes = (const float4 *)c->scratch[0].p;
+    np.presorted_n = boxes_num;
+    np.total_anchors = boxes_num;
+    np.max_det = boxes_num;
+    np.iou_thr = thresh;
+    int *d_total = (int *)c->scratch[1].p;
+    np.out_total = d_total;
+    np.out_gidx = d_total + 2;
+    RFD_TRY(launch_nms(np, 1, c->stream));
+    int total = 0;
+    RFD_HIP(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_HIP(hipMemcpy(keep, d_total + 2, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    *num_out = total;
+    return RFD_OK;
+}
+
+void _nms(int32_t *keep, int *num_out, float *boxes, int boxes_num, int boxes_dim, float thresh, int device_id)
+{
+    if (num_out) *num_out = -1;
+    if (device_id < 0 || device_id >= 16 || !keep || !num_out) return;
+    std::lock_guard<std::mutex> lk(g_nms_mu);
+    if (!g_nms_ctx[device_id]) {
+        rfd_config cfg;
+        rfd_config_default(&cfg);
+        cfg.device_id = device_id;
+        cfg.max_det = 1;
+        if (rfd_create(&cfg, &g_nms_ctx[device_id]) != RFD_OK) { g_nms_ctx[device_id] = nullptr; return; }
+    }
+    if (rfd_nms_sorted(g_nms_ctx[device_id], keep, num_out, boxes, boxes_num, boxes_dim, thresh) != RFD_OK) *num_out = -1;
+}
+
+} // extern "C"

@@ -1,0 +1,99 @@
+// kernels.h -- launch interfaces of the HIP kernels (all gfx950).
+#pragma once
+#include "rfd_common.h"
+
+namespace rfd {
+
+// ---------------------------------------------------------------- preprocess (kernels_pre.hip)
+// One source frame and its letterbox geometry (reference face_detection.rs:131-198).
+struct PreImage {
+    const uint8_t *src; // device, HxWx3 u8 BGR
+    long long stride;   // bytes per source row
+    int h, w;
+    int new_w, new_h;   // resized extent pasted at (0,0) of the canvas
+    int area_fast;      // both scale factors exactly 2: OpenCV's INTER_LINEAR -> INTER_AREA switch
+    int pad;
+    double scale_x, scale_y; // 1 / (new_w / w), 1 / (new_h / h) in f64, as cv::resize computes them
+};
+
+struct PreParams {
+    const PreImage *imgs; // device [n]
+    int net_h, net_w;
+    bf16_t *out_nhwc4;    // [n][net_h][net_w][4] bf16 R,G,B,0  (network input) or null
+    uint8_t *out_det_img; // [n][net_h][net_w][3] u8 BGR canvas (reference det_img) or null
+    float *out_tensor;    // [n][3][net_h][net_w] f32 R,G,B planes (reference Triton input) or null
+};
+int launch_preprocess(const PreParams &p, int n, hipStream_t s);
+// [n][3][H][W] f32 planes -> [n][H][W][4] bf16 (used by rfd_forward, whose input is the tensor)
+int launch_tensor_to_nhwc4(const float *tensor, bf16_t *out, int n, int H, int W, hipStream_t s);
+
+// ---------------------------------------------------------------- decode / sort / NMS (kernels_post.hip)
+struct DecodeParams {
+    const float *cls[kNumLevels];
+    const float *bbox[kNumLevels];
+    const float *lmk[kNumLevels];
+    int fh[kNumLevels], fw[kNumLevels], stride[kNumLevels], level_off[kNumLevels];
+    float base_anchor[kNumLevels][kA][4];
+    int total_anchors;
+    int net_h, net_w;
+    float conf_thr;
+    float *rows;    // [n][total_anchors][16]
+    uint64_t *keys; // [n][total_anchors]
+    int *count;     // [n], zeroed before launch
+};
+int launch_decode(const DecodeParams &p, int n, bool nchw, hipStream_t s);
+
+int launch_sort(const uint64_t *keys, const int *count, const float *rows, uint64_t *sorted_keys,
+                float4 *sorted_boxes, int total_anchors, int n, hipStream_t s);
+
+struct NmsParams {
+    const uint64_t *sorted_keys; // [n][total_anchors] (null with presorted boxes)
+    const float4 *sorted_boxes;  // [n][total_anchors]
+    const float *rows;           // [n][total_anchors][16] (null: emit indices only)
+    const int *count;            // [n]
+    const float *det_scale;      // [n]
+    int presorted_n;             // >= 0: every image has exactly this many boxes (rfd_nms_sorted)
+    int total_anchors;
+    int max_det;
+    int nwords_cap;              // filled by launch_nms
+    float iou_thr;
+    float *out_boxes;            // [n][max_det][5]
+    float *out_lmk;              // [n][max_det][10]
+    int *out_count;              // [n]
+    int *out_total;              // [n]
+    int *out_gidx;               // [n][max_det] or null
+};
+int launch_nms(NmsParams p, int n_images, hipStream_t s);
+
+// ---------------------------------------------------------------- convolution engine (kernels_conv.hip)
+// Activations: NHWC bf16.  Weights: [Cout][KH][KW][Cin] bf16 (K contiguous).  f32 accumulate on MFMA.
+struct ConvParams {
+    const bf16_t *x;      // [B][H][W][Cin]
+    const bf16_t *w;      // [Cout][KH*KW*Cin]
+    const float *bias;    // [Cout] (BN folded)
+    const bf16_t *res;    // residual [B][RH][RW][Cout] or null; added before relu / raw store
+    const float *scale2;  // second output: act = relu(v * scale2 + shift2), or null
+    const float *shift2;
+    bf16_t *y;            // primary output [B][Ho][Wo][ldy] at channel offset y_coff (null: skip)
+    bf16_t *y2;           // activated second output [B][Ho][Wo][Cout] or null
+    float *yf;            // f32 output [B][Ho][Wo][Cout] (heads) or null
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int ldy, y_coff;      // primary output row pitch (channels) and channel offset (SSH concat)
+    int relu;             // relu on the primary output
+    int res_up2;          // residual is half resolution: read at (ho/2, wo/2) (FPN nearest 2x)
+    int res_post;         // add the residual AFTER the ReLU (FPN: relu(lateral) + upsampled)
+    int head_softmax;     // heads: channels [0,4) are cls logits -> 2-class softmax pairs (a, A+a)
+};
+int launch_conv(const ConvParams &p, hipStream_t s);
+// conv0: 7x7 stride 2 pad 3 on the NHWC4 input, fused bias + ReLU -> [B][H/2][W/2][64]
+int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H,
+                 int W, hipStream_t s);
+// 3x3 stride 2 pad 1 max pool, NHWC bf16
+// optional fused per-channel affine + ReLU on the pooled value (scale/shift may be null)
+int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const float *shift, int B, int H,
+                        int W, int C, hipStream_t s);
+// head tensors [B][h][w][32] f32 (cls4 bbox8 lmk20) -> reference NCHW contract (rfd_forward)
+int launch_heads_to_nchw(const float *h32, float *cls, float *bbox, float *lmk, int B, int fh,
+                         int fw, hipStream_t s);
+
+} // namespace rfd

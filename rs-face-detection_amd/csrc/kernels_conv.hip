@@ -1,0 +1,402 @@
+// kernels_conv.hip -- the RetinaFace network's convolutions as implicit GEMM on CDNA4 matrix cores.
+//
+// Replaces the remote Triton forward pass of the reference (face_detection.rs:279 model_infer).
+// Layout: activations NHWC bf16, weights [Cout][KH][KW][Cin] bf16, so both GEMM operands are
+// K-contiguous:  D[n][m] = sum_k W[n][k] * X[m][k],  m = (b,ho,wo), k = (ky,kx,ci).
+// The weight tile is the MFMA A operand and the im2col activation tile the B operand, so every lane
+// ends up with 4 consecutive output CHANNELS of one pixel -> packed 8-byte NHWC stores.
+//
+// Per workgroup (256 threads = 4 wave64): BM x BN output tile, K step 64, both operand tiles
+// staged global -> VGPR -> LDS (XOR-swizzled 128-byte rows: conflict-free ds_read_b128 fragments),
+// double-buffered, one barrier per K step; v_mfma_f32_16x16x32_bf16 with f32 accumulators;
+// epilogue fused: +bias (BN folded), +residual (optionally nearest-2x upsampled), ReLU, second
+// "BN+ReLU" output for pre-activation units, channel-offset stores (SSH concat), f32 + softmax heads.
+#include "kernels.h"
+
+namespace rfd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
+{
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+
+// blockIdx -> tile id such that each XCD (blocks b, b+8, ... share one L2) walks a contiguous chunk
+// of tiles: neighbouring tiles share weight panels / activation halos (bijective for any grid size)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
+{
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int ROWS_PER_PASS = NT / 8;          // 8 x 16-byte chunks per 64-wide K row
+    constexpr int XL = BM / ROWS_PER_PASS, WL = BN / ROWS_PER_PASS;
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/thread mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [2][BM*64]
+    bf16_t *Ws = Xs + 2 * BM * 64;                             // [2][BN*64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.B * HoWo;
+    const int K = p.KH * p.KW * p.Cin;
+    const int tiles_n = p.Cout / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+    // ---- per-thread im2col row bookkeeping (rows tid/8 + ROWS_PER_PASS*i, chunk tid%8) ----
+    const int c8 = tid & 7, r0 = tid >> 3;
+    long long xoff[XL];
+    int hi0[XL], wi0[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int m = m0 + r0 + ROWS_PER_PASS * i;
+        if (m < M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            hi0[i] = ho * p.stride - p.pad;
+            wi0[i] = wo * p.stride - p.pad;
+            xoff[i] = (((long long)b * p.H + hi0[i]) * p.W + wi0[i]) * p.Cin + c8 * 8;
+        } else {
+            hi0[i] = -(1 << 28); // fails every bounds check -> zero rows
+            wi0[i] = 0;
+            xoff[i] = 0;
+        }
+    }
+    const bf16_t *wrow = p.w + (size_t)(n0 + r0) * K + c8 * 8;
+
+    uint4 xr[XL], wr[WL];
+    int ky = 0, kx = 0, kc = 0; // position of the NEXT tile to load
+    const int kc_n = p.Cin >> 6;
+    int kt_load = 0;
+    auto load_tile = [&]() {
+        const long long tap = ((long long)ky * p.W + kx) * p.Cin + (kc << 6);
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const bool ok = (unsigned)(hi0[i] + ky) < (unsigned)p.H && (unsigned)(wi0[i] + kx) < (unsigned)p.W;
+            xr[i] = ok ? *reinterpret_cast<const uint4 *>(p.x + xoff[i] + tap) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            wr[i] = *reinterpret_cast<const uint4 *>(wrow + (size_t)(ROWS_PER_PASS * i) * K + (kt_load << 6));
+        ++kt_load;
+        if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int r = r0 + ROWS_PER_PASS * i;
+            *reinterpret_cast<uint4 *>(Xs + buf * BM * 64 + r * 64 + ((c8 ^ (r & 7)) << 3)) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            const int r = r0 + ROWS_PER_PASS * i;
+            *reinterpret_cast<uint4 *>(Ws + buf * BN * 64 + r * 64 + ((c8 ^ (r & 7)) << 3)) = wr[i];
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K >> 6;
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(); // global loads in flight under the MFMAs below
+        const bf16_t *xs = Xs + buf * BM * 64 + (wm * WM) * 64;
+        const bf16_t *ws = Ws + buf * BN * 64 + (wn * WN) * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TN], bfr[TM];
+            const int ch = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = i * 16 + frow; // (wn*WN) is a multiple of 16, so (row & 7) == (r & 7)
+                af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = j * 16 + frow;
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: lane holds channels n..n+3 of pixel m ----
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + frow;
+        if (m >= M) continue;
+        size_t mr = (size_t)m;
+        if (p.res && p.res_up2) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+            const float4 bias = *reinterpret_cast<const float4 *>(p.bias + n);
+            float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y;
+            float v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
+            float r0f = 0.f, r1f = 0.f, r2f = 0.f, r3f = 0.f;
+            if (p.res) {
+                const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + mr * p.Cout + n);
+                r0f = bf16_bits_to_f32(rv.x & 0xffffu); r1f = bf16_bits_to_f32(rv.x >> 16);
+                r2f = bf16_bits_to_f32(rv.y & 0xffffu); r3f = bf16_bits_to_f32(rv.y >> 16);
+                if (!p.res_post) { v0 += r0f; v1 += r1f; v2 += r2f; v3 += r3f; }
+            }
+            if (p.y) {
+                float o0 = v0, o1 = v1, o2 = v2, o3 = v3;
+                if (p.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
+                if (p.res && p.res_post) { o0 += r0f; o1 += r1f; o2 += r2f; o3 += r3f; }
+                *reinterpret_cast<uint2 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = pack_bf16x4(o0, o1, o2, o3);
+            }
+            if (p.y2) {
+                const float4 s2 = *reinterpret_cast<const float4 *>(p.scale2 + n);
+                const float4 t2 = *reinterpret_cast<const float4 *>(p.shift2 + n);
+                *reinterpret_cast<uint2 *>(p.y2 + (size_t)m * p.Cout + n) =
+                    pack_bf16x4(fmaxf(v0 * s2.x + t2.x, 0.f), fmaxf(v1 * s2.y + t2.y, 0.f),
+                                fmaxf(v2 * s2.z + t2.z, 0.f), fmaxf(v3 * s2.w + t2.w, 0.f));
+            }
+            if (p.yf) {
+                if (p.head_softmax && n == 0) {
+                    // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
+                    const float m0s = fmaxf(v0, v2), m1s = fmaxf(v1, v3);
+                    const float e0 = expf(v0 - m0s), e2 = expf(v2 - m0s);
+                    const float e1 = expf(v1 - m1s), e3 = expf(v3 - m1s);
+                    v0 = e0 / (e0 + e2); v2 = e2 / (e0 + e2);
+                    v1 = e1 / (e1 + e3); v3 = e3 / (e1 + e3);
+                }
+                *reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int grid = ceil_div(M, BM) * (p.Cout / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+int launch_conv(const ConvParams &p, hipStream_t s)
+{
+    if (p.Cin % 64 != 0 || p.Cout % 32 != 0) {
+        set_error("conv: Cin=%d must be a multiple of 64 and Cout=%d of 32", p.Cin, p.Cout);
+        return RFD_ERR_INVALID_ARG;
+    }
+    if (p.Cout % 128 == 0) return launch_conv_cfg<128, 128, 2, 2>(p, s);
+    if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1>(p, s);
+    return launch_conv_cfg<128, 32, 4, 1>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv0: 7x7 stride 2 pad 3, Cin = 3 (+1 zero channel), Cout = 64, fused bias + ReLU.
+// K is laid out as 7 (ky) x 32 (8 kx x 4 channels; kx = 7 and channel 3 carry zero weights), so each
+// ky is exactly one 16x16x32 MFMA K step and a lane's 8-element B fragment is two adjacent input
+// pixels (16 contiguous bytes of the NHWC4 image).  Each wave keeps all 64x224 weights in registers
+// (28 A fragments) and streams 16-pixel output tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv0_kernel(const bf16_t *__restrict__ x4,
+                                                    const bf16_t *__restrict__ w, // [64][7][32]
+                                                    const float *__restrict__ bias,
+                                                    bf16_t *__restrict__ y, int B, int H, int W)
+{
+    const int lane = threadIdx.x & 63, frow = lane & 15, fq = lane >> 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long M = (long long)B * Ho * Wo;
+    const long long ntile = (M + 15) >> 4;
+    bf16x8 af[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            af[i][k] = *reinterpret_cast<const bf16x8 *>(w + ((size_t)(i * 16 + frow) * 7 + k) * 32 + fq * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + fq * 4);
+
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long t = wave_id; t < ntile; t += nwaves) {
+        const long long m = t * 16 + frow;
+        const bool mok = m < M;
+        int b = 0, ho = 0, wo = 0;
+        if (mok) {
+            b = (int)(m / ((long long)Ho * Wo));
+            const int rem = (int)(m - (long long)b * Ho * Wo);
+            ho = rem / Wo;
+            wo = rem - ho * Wo;
+        }
+        const int wi = 2 * wo - 3 + 2 * fq; // first of this lane's two input pixels
+        const bool w0ok = mok && (unsigned)wi < (unsigned)W, w1ok = mok && (unsigned)(wi + 1) < (unsigned)W;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 frag[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int hi = 2 * ho - 3 + k;
+            const bool hok = (unsigned)hi < (unsigned)H;
+            const uint2 *px = reinterpret_cast<const uint2 *>(x4) + ((long long)b * H + hi) * W + wi;
+            const uint2 p0 = (hok && w0ok) ? px[0] : make_uint2(0, 0);
+            const uint2 p1 = (hok && w1ok) ? px[1] : make_uint2(0, 0);
+            frag[k] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, frag[k]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][k], bf, acc[i], 0, 0, 0);
+        }
+        if (mok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<uint2 *>(y + m * 64 + i * 16 + fq * 4) =
+                    pack_bf16x4(fmaxf(acc[i][0] + bv[i].x, 0.f), fmaxf(acc[i][1] + bv[i].y, 0.f),
+                                fmaxf(acc[i][2] + bv[i].z, 0.f), fmaxf(acc[i][3] + bv[i].w, 0.f));
+        }
+    }
+}
+
+int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W,
+                 hipStream_t s)
+{
+    if ((H | W) & 1) {
+        set_error("conv0: input %dx%d must be even", H, W);
+        return RFD_ERR_INVALID_ARG;
+    }
+    const long long ntile = ((long long)B * (H / 2) * (W / 2) + 15) / 16;
+    const int grid = (int)std::min<long long>((ntile + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(conv0_kernel, dim3(grid), dim3(256), 0, s, x4, w, bias, y, B, H, W);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max pool (NHWC bf16), optional fused per-channel affine + ReLU on the output
+// (the BN1+ReLU that opens the first pre-activation unit).  8 channels (16 bytes) per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_kernel(const bf16_t *__restrict__ x, bf16_t *__restrict__ y,
+                                                      const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, int B, int H, int W,
+                                                      int C, int Ho, int Wo)
+{
+    const int cg = C >> 3;
+    const long long total = (long long)B * Ho * Wo * cg;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg) * 8;
+    long long pix = i / cg;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float mx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mx[k] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hi = 2 * ho - 1 + dy;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int wi = 2 * wo - 1 + dx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + (((long long)b * H + hi) * W + wi) * C + c);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mx[2 * k] = fmaxf(mx[2 * k], bf16_bits_to_f32(u[k] & 0xffffu));
+                mx[2 * k + 1] = fmaxf(mx[2 * k + 1], bf16_bits_to_f32(u[k] >> 16));
+            }
+        }
+    }
+    if (scale) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx[k] = fmaxf(mx[k] * scale[c + k] + shift[c + k], 0.f);
+    }
+    const uint2 lo = pack_bf16x4(mx[0], mx[1], mx[2], mx[3]), hi2 = pack_bf16x4(mx[4], mx[5], mx[6], mx[7]);
+    *reinterpret_cast<uint4 *>(y + i * 8) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+}
+
+int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const float *shift, int B, int H,
+                        int W, int C, hipStream_t s)
+{
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, scale,
+                       shift, B, H, W, C, Ho, Wo);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// head tensor [B][h][w][32] f32 -> the reference's three NCHW tensors of one level
+__global__ void __launch_bounds__(256) heads_to_nchw_kernel(const float *__restrict__ h32, float *__restrict__ cls,
+                                                            float *__restrict__ bbox, float *__restrict__ lmk,
+                                                            int B, int hw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x; // over B*32*hw, pos fastest
+    if (i >= (long long)B * 32 * hw) return;
+    const int pos = (int)(i % hw);
+    const int c = (int)((i / hw) % 32);
+    const int b = (int)(i / ((long long)hw * 32));
+    const float v = h32[((size_t)b * hw + pos) * 32 + c];
+    if (c < 4) cls[((size_t)b * 4 + c) * hw + pos] = v;
+    else if (c < 12) bbox[((size_t)b * 8 + (c - 4)) * hw + pos] = v;
+    else lmk[((size_t)b * 20 + (c - 12)) * hw + pos] = v;
+}
+
+int launch_heads_to_nchw(const float *h32, float *cls, float *bbox, float *lmk, int B, int fh, int fw,
+                         hipStream_t s)
+{
+    const long long total = (long long)B * 32 * fh * fw;
+    hipLaunchKernelGGL(heads_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h32, cls,
+                       bbox, lmk, B, fh * fw);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+} // namespace rfd

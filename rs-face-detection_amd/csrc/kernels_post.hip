@@ -1,0 +1,358 @@
+// kernels_post.hip -- everything after the network, on the GPU (gfx950, wave64):
+//   decode + threshold + compact   (reference face_detection.rs:319-408, rcnn/anchors.rs:3-21,
+//                                   processing/bbox_transform.rs:27-45)
+//   deterministic sort             (reference utils.rs:87-95 stable argsort, :97-124 reorder)
+//   greedy NMS + gather + rescale  (reference processing/nms.rs:3-65, face_detection.rs:431-493;
+//                                   replaces the never-built rcnn/nms_kernel.cu)
+//
+// All arithmetic is IEEE f32 in the reference's written operation order; this file is compiled
+// with -ffp-contract=off so no mul+add is fused.  These kernels are HBM/latency bound integer and
+// f32 work -- no MFMA.
+#include "kernels.h"
+
+namespace rfd {
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+
+// Correctly rounded f32 exp through f64 (matches glibc expf, which Rust's f32::exp calls, on all
+// but ~1e-8 of inputs): the 1e-4 coordinate tolerance and identical NMS decisions need the same
+// value the CPU computes, not a 1-ulp-off fast exp.
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+
+__device__ __forceinline__ uint32_t score_sort_bits(float s)
+{
+    // monotone map f32 -> u32 (ascending), then inverted so that ascending key = descending score
+    if (s == 0.0f) s = 0.0f; // -0.0 == +0.0 under partial_cmp
+    uint32_t u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    return ~u;
+}
+
+// One thread per anchor row g (g = level offset + (h*W + w)*A + a).
+// Rows with score >= conf_thr (face_detection.rs:375) are decoded (bbox_pred :516-549,
+// clip_boxes bbox_transform.rs:27-45, landmark_pred :551-570) into rows[b][g][0..15] and their sort
+// key appended to keys[b][*].  Decoding only the survivors is equivalent to the reference's
+// decode-everything-then-select because each row is a pure function of its own inputs.
+template <bool NCHW>
+__global__ void __launch_bounds__(256) decode_kernel(DecodeParams p)
+{
+    const int b = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.total_anchors) return;
+    int l = 0;
+    if (g >= p.level_off[1]) l = 1;
+    if (g >= p.level_off[2]) l = 2;
+    const int r = g - p.level_off[l];
+    const int a = r % kA;
+    const int pos = r / kA;
+    const int fw = p.fw[l], fh = p.fh[l];
+    const int h = pos / fw, w = pos - h * fw;
+    const int stride = p.stride[l];
+    const size_t hw = (size_t)fh * fw;
+
+    float score;
+    if (NCHW) // cls [n][2A][h][w]; fg of anchor a = channel A + a (face_detection.rs:322)
+        score = p.cls[l][((size_t)b * 2 * kA + kA + a) * hw + pos];
+    else      // fused head tensor [n][h][w][32] = cls 2A | bbox 4A | lmk 10A (kernels_conv.hip heads)
+        score = p.cls[l][((size_t)b * hw + pos) * 32 + kA + a];
+    if (!(score >= p.conf_thr)) return;
+
+    float d[4], ld[10];
+    if (NCHW) {
+        const float *bb = p.bbox[l] + ((size_t)b * 4 * kA + 4 * a) * hw + pos;
+        const float *lm = p.lmk[l] + ((size_t)b * 10 * kA + 10 * a) * hw + pos;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = bb[c * hw];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) ld[c] = lm[c * hw];
+    } else {
+        const float *bb = p.cls[l] + ((size_t)b * hw + pos) * 32 + 2 * kA + 4 * a;
+        const float *lm = p.cls[l] + ((size_t)b * hw + pos) * 32 + 6 * kA + 10 * a;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = bb[c];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) ld[c] = lm[c];
+    }
+    // anchor (rcnn/anchors.rs:9-16): base + (w*stride, h*stride, w*stride, h*stride)
+    const float sw = (float)(w * stride), sh = (float)(h * stride);
+    const float ax1 = p.base_anchor[l][a][0] + sw, ay1 = p.base_anchor[l][a][1] + sh;
+    const float ax2 = p.base_anchor[l][a][2] + sw, ay2 = p.base_anchor[l][a][3] + sh;
+    // bbox_pred (face_detection.rs:522-542); bbox_stds = 1 (:366-371)
+    const float bw = ax2 - ax1 + 1.0f;
+    const float bh = ay2 - ay1 + 1.0f;
+    const float cx = ax1 + 0.5f * (bw - 1.0f);
+    const float cy = ay1 + 0.5f * (bh - 1.0f);
+    const float pcx = d[0] * 1.0f * bw + cx;
+    const float pcy = d[1] * 1.0f * bh + cy;
+    const float pw = exp_cr(d[2] * 1.0f) * bw;
+    const float ph = exp_cr(d[3] * 1.0f) * bh;
+    float x1 = pcx - 0.5f * (pw - 1.0f);
+    float y1 = pcy - 0.5f * (ph - 1.0f);
+    float x2 = pcx + 0.5f * (pw - 1.0f);
+    float y2 = pcy + 0.5f * (ph - 1.0f);
+    // clip_boxes (bbox_transform.rs:27-45): v.min(hi).max(0); fminf/fmaxf return the non-NaN operand
+    const float wmax = (float)p.net_w - 1.0f, hmax = (float)p.net_h - 1.0f;
+    x1 = fmaxf(fminf(x1, wmax), 0.0f);
+    y1 = fmaxf(fminf(y1, hmax), 0.0f);
+    x2 = fmaxf(fminf(x2, wmax), 0.0f);
+    y2 = fmaxf(fminf(y2, hmax), 0.0f);
+
+    float4 *row = reinterpret_cast<float4 *>(p.rows + ((size_t)b * p.total_anchors + g) * kDetRow);
+    // landmark_pred (face_detection.rs:557-566): from the ANCHOR, not the decoded box; landmark_std = 1
+    float lo[10];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        lo[2 * k + 0] = ld[2 * k + 0] * 1.0f * bw + cx;
+        lo[2 * k + 1] = ld[2 * k + 1] * 1.0f * bh + cy;
+    }
+    row[0] = make_float4(x1, y1, x2, y2);
+    row[1] = make_float4(score, lo[0], lo[1], lo[2]);
+    row[2] = make_float4(lo[3], lo[4], lo[5], lo[6]);
+    row[3] = make_float4(lo[7], lo[8], lo[9], 0.0f);
+
+    const int slot = atomicAdd(p.count + b, 1);
+    p.keys[(size_t)b * p.total_anchors + slot] = ((uint64_t)score_sort_bits(score) << 32) | (uint32_t)g;
+}
+
+int launch_decode(const DecodeParams &p, int n, bool nchw, hipStream_t s)
+{
+    dim3 grid(ceil_div(p.total_anchors, 256), n);
+    if (nchw)
+        hipLaunchKernelGGL(decode_kernel<true>, grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(decode_kernel<false>, grid, dim3(256), 0, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort: the reference stable-sorts the level-concatenated candidates by score descending
+// (utils.rs:87-95); level concatenation order == ascending g, so the order is the total order
+// (score desc, g asc) = ascending 64-bit key.  Keys are unique, so rank = #{keys smaller} is a
+// permutation: a rank sort needs no stability argument and is deterministic.
+// Also gathers the box of each sorted row into sorted_boxes for the NMS kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rank_sort_kernel(const uint64_t *__restrict__ keys,
+                                                        const int *__restrict__ count,
+                                                        const float *__restrict__ rows,
+                                                        uint64_t *__restrict__ sorted_keys,
+                                                        float4 *__restrict__ sorted_boxes,
+                                                        int total_anchors)
+{
+    __shared__ uint64_t tile[256];
+    const int b = blockIdx.y;
+    const int n = count[b];
+    if ((int)(blockIdx.x * 256) >= n) return; // block-uniform
+    const uint64_t *k = keys + (size_t)b * total_anchors;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t mine = i < n ? k[i] : ~0ull;
+    int rank = 0;
+    for (int t0 = 0; t0 < n; t0 += 256) {
+        const int j = t0 + threadIdx.x;
+        tile[threadIdx.x] = j < n ? k[j] : ~0ull;
+        __syncthreads();
+        const int lim = min(256, n - t0);
+        for (int jj = 0; jj < lim; ++jj) rank += tile[jj] < mine ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < n) {
+        sorted_keys[(size_t)b * total_anchors + rank] = mine;
+        const uint32_t g = (uint32_t)mine;
+        sorted_boxes[(size_t)b * total_anchors + rank] =
+            *reinterpret_cast<const float4 *>(rows + ((size_t)b * total_anchors + g) * kDetRow);
+    }
+}
+
+int launch_sort(const uint64_t *keys, const int *count, const float *rows, uint64_t *sorted_keys,
+                float4 *sorted_boxes, int total_anchors, int n, hipStream_t s)
+{
+    dim3 grid(ceil_div(total_anchors, 256), n);
+    hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, s, keys, count, rows, sorted_keys,
+                       sorted_boxes, total_anchors);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS: wave64 bitmask in LDS.
+//
+// One workgroup per image walks the score-sorted candidates in tiles of 64 (= one wavefront, one
+// 64-bit word of the `removed` bitmap held in LDS).  Per tile: wave 0 builds the 64x64 intra-tile
+// suppression masks (lane i owns row i), resolves the greedy order serially with wave-uniform bit
+// tricks, and emits the kept rows; then all waves test every still-alive later candidate against
+// the KEPT boxes of this tile only and publish one ballot word each -- so the work is O(N*K) like
+// the reference's CPU loop (nms.rs:10-62), not the O(N^2) all-pairs mask of nms_kernel.cu:34-78,
+// and the N x N/64 mask never exists in memory.
+//
+// Survivor rule: a later box survives iff `ovr <= thresh` (nms.rs:58) -- a NaN overlap suppresses.
+// IoU: +1 pixel convention, inter / (area_i + area_j - inter) in f32 (nms.rs:39-54).
+// ------------------------------------------------------------------------------------------------
+constexpr int kNmsThreads = 512;
+constexpr int kNmsWaves = kNmsThreads / 64;
+constexpr int kNmsLdsBoxes = 4096; // sorted boxes cached in LDS (64 KiB); the rest stream from L2
+
+__device__ __forceinline__ float box_area(const float4 b)
+{
+    return (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+}
+
+__device__ __forceinline__ bool suppresses(const float4 bi, const float area_i, const float4 bj,
+                                           const float thresh)
+{
+    const float xx1 = fmaxf(bi.x, bj.x);
+    const float yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z);
+    const float yy2 = fminf(bi.w, bj.w);
+    float w = xx2 - xx1 + 1.0f;
+    float h = yy2 - yy1 + 1.0f;
+    w = fmaxf(0.0f, w);
+    h = fmaxf(0.0f, h);
+    const float inter = w * h;
+    const float area_j = box_area(bj);
+    const float ovr = inter / (area_i + area_j - inter);
+    return !(ovr <= thresh);
+}
+
+__global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve (all offsets multiples of 16)
+    float4 *lds_boxes = reinterpret_cast<float4 *>(smem);                                   // [kNmsLdsBoxes]
+    float4 *tile_boxes = lds_boxes + kNmsLdsBoxes;                                           // [64]
+    uint64_t *removed = reinterpret_cast<uint64_t *>(tile_boxes + 64);                       // [nwords_cap]
+    uint64_t *kept_word = removed + p.nwords_cap;                                            // [2]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.presorted_n >= 0 ? p.presorted_n : p.count[b];
+    const int ntiles = (n + 63) >> 6;
+    const float4 *sb = p.sorted_boxes + (size_t)b * p.total_anchors;
+    const float thresh = p.iou_thr;
+
+    for (int w = tid; w < ntiles; w += kNmsThreads) {
+        const int rem = n - w * 64;
+        removed[w] = rem >= 64 ? 0ull : ~((1ull << rem) - 1ull); // slots >= n are dead
+    }
+    for (int j = tid; j < min(n, kNmsLdsBoxes); j += kNmsThreads) lds_boxes[j] = sb[j];
+    __syncthreads();
+
+    int kept_base = 0; // meaningful in wave 0 only
+    for (int t = 0; t < ntiles; ++t) {
+        if (wave == 0) {
+            const int j = t * 64 + lane;
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < n) box = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
+            tile_boxes[lane] = box;
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t rem_t = removed[t];
+            const uint64_t alive0 =
+                ~(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem_t >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_t));
+            uint64_t kept = 0;
+            if (alive0 != 0ull) {
+                // intra-tile masks: lane i marks every later lane jj it would suppress
+                const float area = box_area(box);
+                uint64_t mask = 0;
+                for (int jj = 0; jj < 64; ++jj) {
+                    // lanes read the same LDS address: a broadcast
+                    const float4 other = tile_boxes[jj];
+                    if (jj > lane && suppresses(box, area, other, thresh)) mask |= 1ull << jj;
+                }
+                // greedy resolve in score order; `alive` is wave-uniform
+                uint64_t alive = alive0;
+                while (alive != 0ull) {
+                    const int i = __builtin_ctzll(alive);
+                    kept |= 1ull << i;
+                    const uint32_t mlo = __builtin_amdgcn_readlane((int)(uint32_t)mask, i);
+                    const uint32_t mhi = __builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), i);
+                    const uint64_t mi = ((uint64_t)mhi << 32) | mlo;
+                    alive &= ~(mi | (1ull << i));
+                }
+                // emit kept rows (face_detection.rs:433-464) rescaled by det_scale (:473-493)
+                if ((kept >> lane) & 1ull) {
+                    const int o = kept_base + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                    if (o < p.max_det) {
+                        uint32_t g = (uint32_t)j;
+                        if (p.rows) {
+                            g = (uint32_t)p.sorted_keys[(size_t)b * p.total_anchors + j];
+                            float *ob = p.out_boxes + ((size_t)b * p.max_det + o) * 5;
+                            const float4 *row = reinterpret_cast<const float4 *>(
+                                p.rows + ((size_t)b * p.total_anchors + g) * kDetRow);
+                            const float sc = p.det_scale[b];
+                            const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+                            ob[0] = r0.x / sc; ob[1] = r0.y / sc; ob[2] = r0.z / sc; ob[3] = r0.w / sc;
+                            ob[4] = r1.x;
+                            float *ol = p.out_lmk + ((size_t)b * p.max_det + o) * 10;
+                            ol[0] = r1.y / sc; ol[1] = r1.z / sc; ol[2] = r1.w / sc;
+                            ol[3] = r2.x / sc; ol[4] = r2.y / sc; ol[5] = r2.z / sc; ol[6] = r2.w / sc;
+                            ol[7] = r3.x / sc; ol[8] = r3.y / sc; ol[9] = r3.z / sc;
+                        }
+                        if (p.out_gidx) p.out_gidx[(size_t)b * p.max_det + o] = (int)g;
+                    }
+                }
+                kept_base += __builtin_popcountll(kept);
+            }
+            if (lane == 0) kept_word[0] = kept;
+        }
+        __syncthreads();
+        const uint64_t kmask = kept_word[0];
+        if (kmask != 0ull) {
+            // every wave owns whole bitmap words: one ballot, one plain LDS store, no atomics
+            for (int w = t + 1 + wave; w < ntiles; w += kNmsWaves) {
+                const uint64_t rw = removed[w];
+                if (rw == ~0ull) continue; // wave-uniform
+                const int j = w * 64 + lane;
+                const bool live = !((rw >> lane) & 1ull);
+                bool sup = false;
+                if (live) {
+                    const float4 bj = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
+                    uint64_t km = kmask;
+                    while (km != 0ull && !sup) {
+                        const int i = __builtin_ctzll(km);
+                        km &= km - 1ull;
+                        const float4 bi = tile_boxes[i];
+                        sup = suppresses(bi, box_area(bi), bj, thresh);
+                    }
+                }
+                const uint64_t bal = __ballot(sup);
+                if (lane == 0 && bal != 0ull) removed[w] = rw | bal;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (p.out_total) p.out_total[b] = kept_base;
+        if (p.out_count) p.out_count[b] = min(kept_base, p.max_det);
+    }
+}
+
+size_t nms_lds_bytes(int total_anchors)
+{
+    const int nwords = ceil_div(total_anchors, 64);
+    const int nwords_cap = (nwords + 1) & ~1;
+    return (size_t)(kNmsLdsBoxes + 64) * sizeof(float4) + (size_t)(nwords_cap + 2) * sizeof(uint64_t);
+}
+
+int launch_nms(NmsParams p, int n_images, hipStream_t s)
+{
+    const int nwords = ceil_div(p.total_anchors, 64);
+    p.nwords_cap = (nwords + 1) & ~1;
+    const size_t lds = nms_lds_bytes(p.total_anchors);
+    if (lds > 160 * 1024) {
+        set_error("NMS bitmap for %d anchors does not fit LDS", p.total_anchors);
+        return RFD_ERR_CAPACITY;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(n_images), dim3(kNmsThreads), lds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+} // namespace rfd

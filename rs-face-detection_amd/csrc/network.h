@@ -1,0 +1,85 @@
+// network.h -- static graph of the build-defined RetinaFace network,
+// its weights, workspace plan and executor.  Replaces the Triton model repository + remote
+// inference of the reference (face_detection.rs:234-312).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace rfd {
+
+struct Layer {
+    std::string name;
+    int cin, cout, kh, kw, stride, pad;
+    int has_affine; // per-channel scale2/shift2 (the BN+ReLU that follows a residual add / the pool)
+    float gain;     // synthetic-init gain on the He std
+    size_t w_off;   // element offset into the bf16 weight buffer
+    size_t w_elems; // device elements (conv0 is stored K-padded: 64*7*32)
+    size_t b_off;   // float offset of bias; scale2 at b_off+cout, shift2 at b_off+2*cout
+};
+
+enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2 };
+
+struct Op {
+    int kind;
+    int layer;
+    int in, out, out2, outf, res; // tensor ids, -1 = none
+    int relu, res_up2, res_post, head_softmax, y_coff;
+};
+
+struct TensorDesc {
+    int C, H, W;
+    int is_f32;
+    int buffer;     // workspace buffer id (assigned by plan())
+    int first, last; // op index range in which the tensor is live
+    size_t bytes_per_image() const { return (size_t)C * H * W * (is_f32 ? 4 : 2); }
+};
+
+struct Graph {
+    int backbone = 0, net_h = 0, net_w = 0;
+    std::vector<Layer> layers;
+    std::vector<Op> ops;
+    std::vector<TensorDesc> tensors;
+    int input = -1;        // NHWC4 bf16 network input
+    int heads[3] = {-1, -1, -1}; // f32 [h][w][32] per level (stride 32,16,8)
+    size_t w_total = 0, b_total = 0;
+    std::vector<size_t> buffer_bytes_per_image; // workspace plan
+
+    int build(int backbone, int net_w, int net_h);
+    double macs_per_image() const; // conv multiply-accumulates (Appendix B: 44.265e9 at 640x640 R50)
+    double layer_macs(int op_index) const;
+
+  private:
+    int add_tensor(int C, int H, int W, int f32 = 0);
+    int add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
+                  int has_affine);
+    int add_conv(int layer, int in, int out, int relu, int res = -1, int out2 = -1, int outf = -1);
+    void build_r50();
+    void plan();
+};
+
+struct Network {
+    Graph g;
+    int max_batch = 0;
+    bool weights_ready = false;
+    bf16_t *d_w = nullptr;
+    float *d_b = nullptr;
+    std::vector<void *> d_buffers;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev; // 2 per op when profiling
+    std::vector<float> op_ms;   // last profiled run
+
+    int create(int backbone, int net_w, int net_h, int max_batch);
+    void destroy();
+    int init_synthetic(uint64_t seed, hipStream_t s);
+    int get_layer(int idx, float *w, float *bias, hipStream_t s);
+    int set_layer(int idx, const float *w, const float *bias, hipStream_t s);
+    int get_affine(int idx, float *scale, float *shift, hipStream_t s);
+    int set_affine(int idx, const float *scale, const float *shift, hipStream_t s);
+    void *tensor_ptr(int t) const { return d_buffers[g.tensors[t].buffer]; }
+    int run(int B, hipStream_t s, int first_op = 0, int last_op = -1);
+    int collect_profile(); // after the stream has drained
+};
+
+} // namespace rfd

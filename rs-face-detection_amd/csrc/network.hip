@@ -1,0 +1,453 @@
+// network.hip -- graph construction, workspace planning, weights and execution of the RetinaFace
+// network (build-defined: SURVEY.md Appendix B; the reference only knows the Triton model name
+// "face_detection_retina", config.rs:25, and the 9-output contract its decode implies).
+#include "network.h"
+
+#include <math.h>
+
+namespace rfd {
+
+// ------------------------------------------------------------------------------------------------
+// Graph
+// ------------------------------------------------------------------------------------------------
+int Graph::add_tensor(int C, int H, int W, int f32)
+{
+    TensorDesc t;
+    t.C = C; t.H = H; t.W = W; t.is_f32 = f32; t.buffer = -1; t.first = 1 << 30; t.last = -1;
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+}
+
+int Graph::add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
+                     int has_affine)
+{
+    Layer L;
+    L.name = name; L.cin = cin; L.cout = cout; L.kh = k; L.kw = k; L.stride = stride; L.pad = pad;
+    L.gain = gain; L.has_affine = has_affine;
+    L.w_off = w_total;
+    L.w_elems = (k == 7 && cin == 3) ? (size_t)cout * 7 * 32 : (size_t)cout * k * k * cin;
+    w_total += (L.w_elems + 63) & ~(size_t)63; // keep every layer 128-byte aligned
+    L.b_off = b_total;
+    b_total += (size_t)3 * cout;
+    layers.push_back(L);
+    return (int)layers.size() - 1;
+}
+
+int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int outf)
+{
+    Op o;
+    o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
+    o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
+    ops.push_back(o);
+    return (int)ops.size() - 1;
+}
+
+// RetinaFace-R50: pre-activation ResNet-50 (units 3,4,6,3; stride on the 3x3) + 256-ch FPN + SSH
+// context modules + 1x1 heads (A = 2), every BN folded into the preceding conv or applied as the
+// post-add affine of the previous unit's epilogue.  82 convolutions (the 9 head convs run as three
+// fused N = 32 GEMMs).
+void Graph::build_r50()
+{
+    const int H = net_h, W = net_w;
+    input = add_tensor(4, H, W);
+    const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1);
+    const int t_c0 = add_tensor(64, H / 2, W / 2);
+    {
+        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, 1, 0, 0, 0, 0};
+        ops.push_back(o);
+    }
+    const int t_p = add_tensor(64, H / 4, W / 4);
+    {
+        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, 1, 0, 0, 0, 0};
+        ops.push_back(o);
+    }
+    static const int units[4] = {3, 4, 6, 3};
+    static const int mids[4] = {64, 128, 256, 512};
+    int x_act = t_p, x_raw = -1, cin = 64, h = H / 4, w = W / 4;
+    int c_out[4] = {-1, -1, -1, -1};
+    for (int s = 0; s < 4; ++s) {
+        const int mid = mids[s], cout = mid * 4;
+        for (int u = 0; u < units[s]; ++u) {
+            const int stride = (s > 0 && u == 0) ? 2 : 1;
+            const bool dim_match = u > 0;
+            const int ho = h / stride, wo = w / stride;
+            char nm[64];
+            snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 1);
+            const int l1 = add_layer(nm, cin, mid, 1, 1, 0, 1.0f, 0);
+            const int t1 = add_tensor(mid, h, w);
+            add_conv(l1, x_act, t1, 1);
+            snprintf(nm, sizeof nm, "stage%d_unit%d_conv2", s + 1, u + 1);
+            const int l2 = add_layer(nm, mid, mid, 3, stride, 1, 1.0f, 0);
+            const int t2 = add_tensor(mid, ho, wo);
+            add_conv(l2, t1, t2, 1);
+            int res = x_raw;
+            if (!dim_match) {
+                snprintf(nm, sizeof nm, "stage%d_unit%d_sc", s + 1, u + 1);
+                const int ls = add_layer(nm, cin, cout, 1, stride, 0, 1.0f, 0);
+                res = add_tensor(cout, ho, wo);
+                add_conv(ls, x_act, res, 0);
+            }
+            snprintf(nm, sizeof nm, "stage%d_unit%d_conv3", s + 1, u + 1);
+            const int l3 = add_layer(nm, mid, cout, 1, 1, 0, 1.0f, 1);
+            const bool need_raw = u + 1 < units[s];
+            const int t_raw = need_raw ? add_tensor(cout, ho, wo) : -1;
+            const int t_act = add_tensor(cout, ho, wo);
+            add_conv(l3, t2, t_raw, 0, res, t_act);
+            x_raw = t_raw; x_act = t_act; cin = cout; h = ho; w = wo;
+        }
+        c_out[s] = x_act;
+    }
+    // FPN (c1 = stage2 out @ /8, c2 = stage3 out @ /16, c3 = stage4 out @ /32)
+    const int c1 = c_out[1], c2 = c_out[2], c3 = c_out[3];
+    auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
+    const int lat3 = add_layer("fpn_lat3", 2048, 256, 1, 1, 0, 1.0f, 0);
+    const int p3 = add_tensor(256, T(c3).H, T(c3).W);
+    add_conv(lat3, c3, p3, 1);
+    const int lat2 = add_layer("fpn_lat2", 1024, 256, 1, 1, 0, 1.0f, 0);
+    const int p2pre = add_tensor(256, T(c2).H, T(c2).W);
+    {
+        const int o = add_conv(lat2, c2, p2pre, 1, p3);
+        ops[o].res_up2 = 1; ops[o].res_post = 1;
+    }
+    const int ag2 = add_layer("fpn_aggr2", 256, 256, 3, 1, 1, 0.8f, 0);
+    const int p2 = add_tensor(256, T(c2).H, T(c2).W);
+    add_conv(ag2, p2pre, p2, 1);
+    const int lat1 = add_layer("fpn_lat1", 512, 256, 1, 1, 0, 1.0f, 0);
+    const int p1pre = add_tensor(256, T(c1).H, T(c1).W);
+    {
+        const int o = add_conv(lat1, c1, p1pre, 1, p2);
+        ops[o].res_up2 = 1; ops[o].res_post = 1;
+    }
+    const int ag1 = add_layer("fpn_aggr1", 256, 256, 3, 1, 1, 0.8f, 0);
+    const int p1 = add_tensor(256, T(c1).H, T(c1).W);
+    add_conv(ag1, p1pre, p1, 1);
+
+    // SSH context module + fused heads per level, order = reference slot order 32,16,8
+    const int feats[3] = {p3, p2, p1};
+    for (int l = 0; l < 3; ++l) {
+        const int f = feats[l], fh = T(f).H, fw = T(f).W, st = kStrides[l];
+        char nm[64];
+        const int o = add_tensor(256, fh, fw);
+        snprintf(nm, sizeof nm, "ssh%d_conv1", st);
+        add_conv(add_layer(nm, 256, 128, 3, 1, 1, 1.0f, 0), f, o, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx1", st);
+        const int tc = add_tensor(64, fh, fw);
+        add_conv(add_layer(nm, 256, 64, 3, 1, 1, 1.0f, 0), f, tc, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx2", st);
+        ops[add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), tc, o, 1)].y_coff = 128;
+        snprintf(nm, sizeof nm, "ssh%d_ctx3a", st);
+        const int td = add_tensor(64, fh, fw);
+        add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), tc, td, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx3b", st);
+        ops[add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), td, o, 1)].y_coff = 192;
+        snprintf(nm, sizeof nm, "head%d", st);
+        heads[l] = add_tensor(32, fh, fw, 1);
+        ops[add_conv(add_layer(nm, 256, 32, 1, 1, 0, 1.0f, 0), o, -1, 0, -1, -1, heads[l])].head_softmax = 1;
+    }
+}
+
+void Graph::plan()
+{
+    const int nops = (int)ops.size();
+    auto touch = [&](int t, int i, bool write) {
+        if (t < 0) return;
+        TensorDesc &d = tensors[t];
+        if (write) d.first = std::min(d.first, i);
+        d.last = std::max(d.last, i);
+    };
+    tensors[input].first = -1;
+    for (int i = 0; i < nops; ++i) {
+        const Op &o = ops[i];
+        touch(o.in, i, false);
+        touch(o.res, i, false);
+        touch(o.out, i, true);
+        touch(o.out2, i, true);
+        touch(o.outf, i, true);
+    }
+    for (int l = 0; l < 3; ++l) tensors[heads[l]].last = nops; // consumed by decode after the net
+    buffer_bytes_per_image.clear();
+    std::vector<int> free_list;
+    auto assign = [&](int t) {
+        TensorDesc &d = tensors[t];
+        if (d.buffer >= 0) return;
+        const size_t need = d.bytes_per_image();
+        int best = -1;
+        for (size_t k = 0; k < free_list.size(); ++k) {
+            const int bi = free_list[k];
+            if (buffer_bytes_per_image[bi] >= need &&
+                (best < 0 || buffer_bytes_per_image[bi] < buffer_bytes_per_image[free_list[best]]))
+                best = (int)k;
+        }
+        if (best >= 0) {
+            d.buffer = free_list[best];
+            free_list.erase(free_list.begin() + best);
+        } else {
+            buffer_bytes_per_image.push_back(need);
+            d.buffer = (int)buffer_bytes_per_image.size() - 1;
+        }
+    };
+    assign(input);
+    for (int i = 0; i < nops; ++i) {
+        for (size_t t = 0; t < tensors.size(); ++t) // release tensors dead before op i
+            if (tensors[t].buffer >= 0 && tensors[t].last == i - 1 && tensors[t].last < nops)
+                free_list.push_back(tensors[t].buffer);
+        const Op &o = ops[i];
+        if (o.out >= 0) assign(o.out);
+        if (o.out2 >= 0) assign(o.out2);
+        if (o.outf >= 0) assign(o.outf);
+    }
+}
+
+int Graph::build(int backbone_, int w, int h)
+{
+    backbone = backbone_; net_w = w; net_h = h;
+    if (w <= 0 || h <= 0 || (w % 32) != 0 || (h % 32) != 0) {
+        set_error("image_size (%d,%d) must be positive multiples of 32", w, h);
+        return RFD_ERR_INVALID_ARG;
+    }
+    if (backbone == RFD_BACKBONE_R50) {
+        build_r50();
+    } else {
+        set_error("backbone %d is not implemented in this build", backbone);
+        return RFD_ERR_INVALID_ARG;
+    }
+    plan();
+    return RFD_OK;
+}
+
+double Graph::layer_macs(int i) const
+{
+    const Op &o = ops[i];
+    if (o.kind == OP_POOL) return 0.0;
+    const Layer &L = layers[o.layer];
+    const int t = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
+    return (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
+}
+
+double Graph::macs_per_image() const
+{
+    double s = 0;
+    for (size_t i = 0; i < ops.size(); ++i) s += layer_macs((int)i);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Network
+// ------------------------------------------------------------------------------------------------
+int Network::create(int backbone, int net_w, int net_h, int max_batch_)
+{
+    RFD_TRY(g.build(backbone, net_w, net_h));
+    max_batch = max_batch_;
+    RFD_HIP(hipMalloc((void **)&d_w, g.w_total * sizeof(bf16_t)));
+    RFD_HIP(hipMalloc((void **)&d_b, g.b_total * sizeof(float)));
+    d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
+    for (size_t i = 0; i < d_buffers.size(); ++i)
+        RFD_HIP(hipMalloc(&d_buffers[i], g.buffer_bytes_per_image[i] * (size_t)max_batch));
+    return RFD_OK;
+}
+
+void Network::destroy()
+{
+    if (d_w) (void)hipFree(d_w);
+    if (d_b) (void)hipFree(d_b);
+    for (void *p : d_buffers)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    d_w = nullptr; d_b = nullptr; d_buffers.clear(); ev.clear();
+}
+
+static inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+struct Gauss { // counter-based Box-Muller: element i of stream `key`
+    uint64_t key;
+    void pair(uint64_t i, float &a, float &b) const
+    {
+        const uint64_t r1 = splitmix64(key + 2 * i), r2 = splitmix64(key + 2 * i + 1);
+        const double u1 = ((double)(r1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+        const double u2 = (double)(r2 >> 11) * (1.0 / 9007199254740992.0);
+        const double rr = sqrt(-2.0 * log(u1)), th = 6.283185307179586 * u2;
+        a = (float)(rr * cos(th));
+        b = (float)(rr * sin(th));
+    }
+};
+
+// Seeded random weights (there is no model file anywhere in the reference): He-scaled so that
+// activations stay O(1) through the 50+ layers in bf16; post-add affines ~ 1/sqrt(1+u).
+int Network::init_synthetic(uint64_t seed, hipStream_t s)
+{
+    int unit_in_stage = 0;
+    for (size_t li = 0; li < g.layers.size(); ++li) {
+        const Layer &L = g.layers[li];
+        const size_t n = (size_t)L.cout * L.kh * L.kw * L.cin;
+        std::vector<float> w(n + 1), b(L.cout), sc(L.cout), sh(L.cout);
+        const float stdv = sqrtf(2.0f / (float)(L.kh * L.kw * L.cin)) * L.gain;
+        Gauss gw{splitmix64(seed * 1315423911ull + li * 2654435761ull)};
+        for (size_t i = 0; i < n; i += 2) {
+            float a, c;
+            gw.pair(i / 2, a, c);
+            w[i] = a * stdv;
+            w[i + 1] = c * stdv;
+        }
+        Gauss gb{splitmix64(seed * 7919ull + li * 104729ull + 17)};
+        const bool head = L.name.compare(0, 4, "head") == 0;
+        if (L.name.find("unit1_conv3") != std::string::npos) unit_in_stage = 1;
+        else if (L.name.find("_conv3") != std::string::npos) ++unit_in_stage;
+        for (int c = 0; c < L.cout; c += 2) {
+            float a, d;
+            gb.pair(c / 2, a, d);
+            b[c] = 0.05f * a;
+            if (c + 1 < L.cout) b[c + 1] = 0.05f * d;
+            float e, f;
+            gb.pair(1000000 + c / 2, e, f);
+            const float base = L.name == "conv0" ? 1.0f : 1.0f / sqrtf(1.0f + (float)unit_in_stage);
+            sc[c] = base * (1.0f + 0.1f * fmaxf(-2.f, fminf(2.f, e)));
+            sh[c] = 0.05f * f;
+            if (c + 1 < L.cout) { sc[c + 1] = base * (1.0f - 0.1f * fmaxf(-2.f, fminf(2.f, e))); sh[c + 1] = -0.05f * f; }
+        }
+        if (head) {
+            // channels: 0,1 bg logits, 2,3 fg logits, 4..11 box deltas, 12..31 landmark deltas.
+            // fg-bg logit difference ~ N(-2, ~1): a fraction of a percent of anchors pass 0.7.
+            const size_t K = (size_t)L.kh * L.kw * L.cin;
+            for (int c = 0; c < L.cout; ++c) {
+                const float g2 = c < 4 ? 0.6f : (c < 12 ? 0.25f : 0.35f);
+                for (size_t k = 0; k < K; ++k) w[c * K + k] *= g2;
+                b[c] = c < 2 ? 1.0f : (c < 4 ? -1.0f : 0.0f);
+            }
+        }
+        RFD_TRY(set_layer((int)li, w.data(), b.data(), s));
+        if (L.has_affine) RFD_TRY(set_affine((int)li, sc.data(), sh.data(), s));
+    }
+    RFD_HIP(hipStreamSynchronize(s));
+    weights_ready = true;
+    return RFD_OK;
+}
+
+int Network::set_layer(int idx, const float *w, const float *bias, hipStream_t s)
+{
+    if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
+    const Layer &L = g.layers[idx];
+    std::vector<bf16_t> hw(L.w_elems, 0);
+    if (L.kh == 7 && L.cin == 3) { // [64][7][7][3] -> [64][7][8 kx][4 c], zero padded
+        for (int n = 0; n < L.cout; ++n)
+            for (int ky = 0; ky < 7; ++ky)
+                for (int kx = 0; kx < 7; ++kx)
+                    for (int c = 0; c < 3; ++c)
+                        hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c] = f32_to_bf16_host(w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c]);
+    } else {
+        for (size_t i = 0; i < L.w_elems; ++i) hw[i] = f32_to_bf16_host(w[i]);
+    }
+    RFD_HIP(hipMemcpyAsync(d_w + L.w_off, hw.data(), L.w_elems * sizeof(bf16_t), hipMemcpyHostToDevice, s));
+    if (bias) RFD_HIP(hipMemcpyAsync(d_b + L.b_off, bias, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipStreamSynchronize(s)); // hw goes out of scope
+    return RFD_OK;
+}
+
+int Network::get_layer(int idx, float *w, float *bias, hipStream_t s)
+{
+    if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
+    const Layer &L = g.layers[idx];
+    if (w) {
+        std::vector<bf16_t> hw(L.w_elems);
+        RFD_HIP(hipMemcpyAsync(hw.data(), d_w + L.w_off, L.w_elems * sizeof(bf16_t), hipMemcpyDeviceToHost, s));
+        RFD_HIP(hipStreamSynchronize(s));
+        if (L.kh == 7 && L.cin == 3) {
+            for (int n = 0; n < L.cout; ++n)
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx)
+                        for (int c = 0; c < 3; ++c)
+                            w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c] = bf16_to_f32_host(hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c]);
+        } else {
+            for (size_t i = 0; i < L.w_elems; ++i) w[i] = bf16_to_f32_host(hw[i]);
+        }
+    }
+    if (bias) {
+        RFD_HIP(hipMemcpyAsync(bias, d_b + L.b_off, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+        RFD_HIP(hipStreamSynchronize(s));
+    }
+    return RFD_OK;
+}
+
+int Network::set_affine(int idx, const float *scale, const float *shift, hipStream_t s)
+{
+    if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
+    const Layer &L = g.layers[idx];
+    RFD_HIP(hipMemcpyAsync(d_b + L.b_off + L.cout, scale, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipMemcpyAsync(d_b + L.b_off + 2 * L.cout, shift, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipStreamSynchronize(s));
+    return RFD_OK;
+}
+
+int Network::get_affine(int idx, float *scale, float *shift, hipStream_t s)
+{
+    if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
+    const Layer &L = g.layers[idx];
+    RFD_HIP(hipMemcpyAsync(scale, d_b + L.b_off + L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+    RFD_HIP(hipMemcpyAsync(shift, d_b + L.b_off + 2 * L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+    RFD_HIP(hipStreamSynchronize(s));
+    return RFD_OK;
+}
+
+int Network::run(int B, hipStream_t s, int first_op, int last_op)
+{
+    if (!weights_ready) { set_error("network weights are not initialised (rfd_init_synthetic_weights / rfd_set_layer_weights)"); return RFD_ERR_STATE; }
+    if (B < 1 || B > max_batch) { set_error("batch %d exceeds max_batch_size %d", B, max_batch); return RFD_ERR_CAPACITY; }
+    const int nops = (int)g.ops.size();
+    if (profiling && (int)ev.size() < 2 * nops) {
+        const size_t old = ev.size();
+        ev.resize(2 * nops);
+        for (size_t i = old; i < ev.size(); ++i) RFD_HIP(hipEventCreate(&ev[i]));
+    }
+    if (last_op < 0 || last_op >= nops) last_op = nops - 1;
+    for (int i = std::max(first_op, 0); i <= last_op; ++i) {
+        const Op &o = g.ops[i];
+        const Layer &L = g.layers[o.layer];
+        const TensorDesc &tin = g.tensors[o.in];
+        if (profiling) RFD_HIP(hipEventRecord(ev[2 * i], s));
+        if (o.kind == OP_CONV0) {
+            RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off,
+                                 (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+        } else if (o.kind == OP_POOL) {
+            RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
+                                        d_b + L.b_off + L.cout, d_b + L.b_off + 2 * L.cout, B, tin.H, tin.W,
+                                        tin.C, s));
+        } else {
+            const int tout = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
+            ConvParams p;
+            memset(&p, 0, sizeof p);
+            p.x = (const bf16_t *)tensor_ptr(o.in);
+            p.w = d_w + L.w_off;
+            p.bias = d_b + L.b_off;
+            p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
+            p.scale2 = d_b + L.b_off + L.cout;
+            p.shift2 = d_b + L.b_off + 2 * L.cout;
+            p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out) : nullptr;
+            p.y2 = o.out2 >= 0 ? (bf16_t *)tensor_ptr(o.out2) : nullptr;
+            p.yf = o.outf >= 0 ? (float *)tensor_ptr(o.outf) : nullptr;
+            p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin; p.Cout = L.cout;
+            p.KH = L.kh; p.KW = L.kw; p.stride = L.stride; p.pad = L.pad;
+            p.Ho = g.tensors[tout].H; p.Wo = g.tensors[tout].W;
+            p.ldy = o.out >= 0 ? g.tensors[o.out].C : L.cout;
+            p.y_coff = o.y_coff;
+            p.relu = o.relu; p.res_up2 = o.res_up2; p.res_post = o.res_post; p.head_softmax = o.head_softmax;
+            RFD_TRY(launch_conv(p, s));
+        }
+        if (profiling) RFD_HIP(hipEventRecord(ev[2 * i + 1], s));
+    }
+    return RFD_OK;
+}
+
+int Network::collect_profile()
+{
+    const int nops = (int)g.ops.size();
+    op_ms.assign(nops, 0.f);
+    if (!profiling || (int)ev.size() < 2 * nops) return RFD_OK;
+    for (int i = 0; i < nops; ++i) RFD_HIP(hipEventElapsedTime(&op_ms[i], ev[2 * i], ev[2 * i + 1]));
+    return RFD_OK;
+}
+
+} // namespace rfd

@@ -1,0 +1,87 @@
+"""CPU tests of the drop-in boundary: librfd_hip.so loads without a GPU, exports every symbol that
+include/rfd.h declares, describes the build-defined graph, and refuses to run without a device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "rfd.h")).read()
+    return sorted(set(re.findall(r"RFD_API\s+[\w \*]+?\b(rfd_\w+|_nms)\s*\(", txt)))
+
+
+def test_header_symbols_exported(rfd):
+    declared = _declared()
+    assert len(declared) >= 30
+    L = rfd.load_library()
+    for name in declared:
+        assert hasattr(L, name), "librfd_hip.so does not export %s" % name
+    assert sorted(rfd.API_SYMBOLS) == declared
+
+
+def test_exports_only_the_c_abi(rfd):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rfd.LIB_PATH]).decode()
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert sorted(syms) == _declared()  # no C++ symbols leak; plain C names only
+
+
+def test_graph_matches_survey_appendix_b(rfd):
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    assert abs(g.macs - 44.2646528e9) < 1e3          # 44.265 GMAC / image
+    convs = [o for o in g.ops if o.kind in (0, 2)]
+    heads = [o for o in g.ops if o.head_softmax]
+    assert len(convs) + 2 * len(heads) == 82           # 9 head convs run as 3 fused N=32 GEMMs
+    assert sorted(t.head_level for t in g.tensors if t.head_level) == [1, 2, 3]
+    hl = {t.head_level: (t.height, t.width, t.channels) for t in g.tensors if t.head_level}
+    assert hl == {1: (20, 20, 32), 2: (40, 40, 32), 3: (80, 80, 32)}
+    params = sum(l.cout * l.kh * l.kw * l.cin for l in g.layers)
+    assert abs(params - 27.24e6) < 0.05e6              # 27.24 M conv parameters
+    # 1920x1088 input: 225.75 GMAC (Appendix B)
+    g2 = rfd.Graph(rfd.BACKBONE_R50, 1920, 1088)
+    assert abs(g2.macs / 1e9 - 225.75) < 0.01
+
+
+def test_graph_plan_has_no_aliasing(rfd):
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    # tensors that share a buffer must have disjoint live ranges: an op never reads and writes one buffer
+    for o in g.ops:
+        outs = [t for t in (o.out, o.out2, o.outf) if t >= 0]
+        ins = [t for t in (o.in_, o.res) if t >= 0]
+        ob = [g.tensors[t].buffer for t in outs]
+        assert len(set(ob)) == len(ob)
+        assert not set(ob) & {g.tensors[t].buffer for t in ins}
+
+
+def test_bad_graph_arguments(rfd):
+    with pytest.raises(rfd.RfdError) as e:
+        rfd.Graph(rfd.BACKBONE_R50, 641, 640)
+    assert e.value.status == rfd.RFD_ERR_INVALID_ARG
+    with pytest.raises(rfd.RfdError):
+        rfd.Graph(7, 640, 640)
+
+
+def test_missing_library_fails_loudly(rfd):
+    with pytest.raises(ImportError):
+        rfd.load_library("/nonexistent/librfd_hip.so")
+
+
+def test_no_device_no_fallback(rfd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rfd.RfdError) as e:
+        rfd.RetinaFaceDetection()
+    assert e.value.status == rfd.RFD_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+    # the reference-compatible `_nms` reports failure through num_out = -1 instead of printing
+    L = rfd.load_library()
+    keep = (ctypes.c_int32 * 4)()
+    num = ctypes.c_int(0)
+    boxes = (ctypes.c_float * 20)()
+    L._nms(keep, ctypes.byref(num), boxes, 4, 5, 0.4, 0)
+    assert num.value == -1

@@ -1,0 +1,173 @@
+"""CPU tests: the oracle (oracle/rfd_oracle.c) against the known answers derived from the literal
+inputs of the reference's own print-only tests (tests/golden/kat_reference_inputs.json) and against
+size-independent properties of the reference algorithm.  Parity status of the oracle itself:
+"parity unpinned" (the reference holds no expected outputs) -- see DESIGN.md."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import helpers
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_reference_inputs.json")))
+
+
+def test_nms_kat(oracle):
+    k = KAT["nms"]
+    for thr, keep in zip(k["thr"], k["keep"]):
+        assert oracle.nms(np.array(k["boxes"], np.float32), thr).tolist() == keep
+
+
+def test_anchor_kats(oracle):
+    k = KAT["anchor_plane"]
+    out = oracle.anchor_plane(k["height"], k["width"], k["stride"], k["base"])
+    assert np.array_equal(out, np.array(k["out"], np.float32))
+    assert np.array_equal(oracle.anchors_fpn(), np.array(KAT["anchors_fpn"]["out"], np.float32))
+
+
+def test_decode_kats(oracle):
+    k = KAT["bbox_pred"]
+    got = oracle.bbox_pred(k["boxes"], k["deltas"])
+    assert np.array_equal(got, np.array(k["out"], np.float32))
+    k = KAT["landmark_pred"]
+    got = oracle.landmark_pred(k["boxes"], k["deltas"]).reshape(2, 10)
+    assert np.array_equal(got, np.array(k["out"], np.float32))
+    k = KAT["clip_boxes"]
+    b = np.array(k["boxes"], np.float32).reshape(-1, 4)
+    got = oracle.clip_boxes(b, *k["im_shape"]).reshape(2, 8)
+    assert np.array_equal(got, np.array(k["out"], np.float32))
+
+
+def test_geometry_kats(oracle):
+    for c in KAT["geometry"]["cases"]:
+        nw, nh, sc = oracle.geometry(c["h"], c["w"])
+        assert (nw, nh) == (c["out"][0], c["out"][1])
+        assert sc == np.float32(c["out"][2])
+
+
+def test_clip_nan_semantics(oracle):
+    # Rust f32::min/max return the non-NaN operand: NaN.min(hi).max(0) == hi
+    b = np.array([[np.nan, -5.0, 1e9, np.inf]], np.float32)
+    assert oracle.clip_boxes(b, 640, 640).tolist() == [[639.0, 0.0, 639.0, 639.0]]
+
+
+def test_argsort_is_stable(oracle):
+    s = np.array([0.9, 0.8, 0.9, 0.7, 0.8, 0.9], np.float32)
+    assert oracle.argsort_desc(s).tolist() == [0, 2, 5, 1, 4, 3]
+
+
+def _rand_dets(rng, n, span=300.0):
+    xy = rng.uniform(0, span, size=(n, 2))
+    wh = rng.uniform(5, 120, size=(n, 2))
+    sc = rng.uniform(0.1, 1.0, size=(n, 1))
+    return np.concatenate([xy, xy + wh, sc], 1).astype(np.float32)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(1, 120), st.floats(0.05, 0.9))
+def test_nms_properties(seed, n, thr):
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    d = _rand_dets(rng, n)
+    keep = O.nms(d, thr)
+    # keep is a subset, in non-increasing score order, starting with the global best
+    assert len(set(keep.tolist())) == len(keep) and all(0 <= i < n for i in keep)
+    assert np.all(np.diff(d[keep, 4]) <= 0)
+    assert d[keep[0], 4] == d[:, 4].max()
+    # idempotent: running NMS on the survivors keeps all of them
+    assert O.nms(d[keep], thr).tolist() == list(range(len(keep)))
+    # no two survivors overlap above the threshold; every suppressed box overlaps a better survivor
+    def iou(a, b):
+        w = max(0.0, np.float32(min(a[2], b[2]) - max(a[0], b[0]) + np.float32(1)))
+        h = max(0.0, np.float32(min(a[3], b[3]) - max(a[1], b[1]) + np.float32(1)))
+        i = np.float32(w) * np.float32(h)
+        sa = (a[2] - a[0] + np.float32(1)) * (a[3] - a[1] + np.float32(1))
+        sb = (b[2] - b[0] + np.float32(1)) * (b[3] - b[1] + np.float32(1))
+        return i / (sa + sb - i)
+    for x in range(len(keep)):
+        for y in range(x + 1, len(keep)):
+            assert iou(d[keep[x]], d[keep[y]]) <= np.float32(thr)
+    # permuting the input rows does not change the kept SET when scores are distinct
+    if len(np.unique(d[:, 4])) == n:
+        p = rng.permutation(n)
+        assert sorted(p[O.nms(d[p], thr)].tolist()) == sorted(keep.tolist())
+
+
+def test_decode_nms_matches_stagewise_composition(oracle):
+    """rfd_oracle_decode_nms == anchors -> bbox_pred -> clip -> threshold -> stable sort -> nms,
+    composed in numpy from the single-stage oracle functions (face_detection.rs:319-470)."""
+    H = W = 128
+    heads = [h[0] for h in helpers.make_heads(7, 1, H, W, cand_rate=0.2, n_faces=3)]
+    det, lmk, gidx, ncand = oracle.decode_nms(heads, H, W, 0.7, 0.45, det_scale=0.5)
+    base = oracle.anchors_fpn()
+    props, scores, lms, gids = [], [], [], []
+    goff = 0
+    for l, s in enumerate((32, 16, 8)):
+        fh, fw = H // s, W // s
+        plane = oracle.anchor_plane(fh, fw, s, base[l]).reshape(-1, 4)
+        cls, bb, lm = heads[3 * l: 3 * l + 3]
+        sc = cls[2:].transpose(1, 2, 0).reshape(-1)
+        dl = bb.transpose(1, 2, 0).reshape(-1, 4)
+        ld = lm.transpose(1, 2, 0).reshape(-1, 5, 2)
+        boxes = oracle.clip_boxes(oracle.bbox_pred(plane, dl), H, W)
+        lp = oracle.landmark_pred(plane, ld)
+        sel = np.nonzero(sc >= np.float32(0.7))[0]
+        props.append(boxes[sel]); scores.append(sc[sel]); lms.append(lp[sel]); gids.append(sel + goff)
+        goff += fh * fw * 2
+    props, scores, lms, gids = map(np.concatenate, (props, scores, lms, gids))
+    assert ncand == len(scores)
+    order = oracle.argsort_desc(scores)
+    pre = np.concatenate([props[order], scores[order, None]], 1)
+    keep = oracle.nms(pre, 0.45)
+    assert np.array_equal(gidx, gids[order][keep])
+    assert np.array_equal(det[:, 4], pre[keep, 4])
+    assert np.array_equal(det[:, :4], pre[keep, :4] / np.float32(0.5))
+    assert np.array_equal(lmk, lms[order][keep] / np.float32(0.5))
+
+
+def test_golden_heads_fixture(oracle):
+    """The committed seeded fixture (tests/golden/make_golden.py) is reproduced bit for bit."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads_128.npz"))
+    heads = [z["h%d" % i] for i in range(9)]
+    det, lmk, gidx, _ = oracle.decode_nms(heads, 128, 128, 0.7, 0.45, det_scale=float(z["det_scale"]))
+    assert np.array_equal(det, z["det"]) and np.array_equal(lmk, z["lmk"]) and np.array_equal(gidx, z["gidx"])
+
+
+def test_empty_and_special_values(oracle):
+    H = W = 64
+    heads = [h[0] for h in helpers.make_heads(3, 1, H, W, cand_rate=0.0)]
+    det, lmk, gidx, ncand = oracle.decode_nms(heads, H, W)
+    assert det.shape == (0, 5) and lmk.shape == (0, 5, 2) and ncand == 0
+    # NaN scores fail `>= thr`; huge dw overflows exp to +inf and is clipped to the frame
+    heads = [h[0].copy() for h in helpers.make_heads(4, 1, H, W, cand_rate=0.5)]
+    heads[0][2:] = np.nan
+    heads[4][2] = 100.0
+    det, lmk, gidx, ncand = oracle.decode_nms(heads, H, W)
+    assert np.all(gidx >= 8) and np.all(np.isfinite(det))
+    assert np.all(det[:, :4] >= 0) and np.all(det[:, :4] <= 63)
+
+
+def test_resize_identity_area_and_bounds(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(img, 37, 53), img)          # scale 1: identity
+    big = rng.integers(0, 256, size=(40, 60, 3), dtype=np.uint8)
+    half = oracle.resize_linear(big, 20, 30)                               # exact 2x: 2x2 mean
+    ref = (big.astype(np.int32).reshape(20, 2, 30, 2, 3).sum(axis=(1, 3)) + 2) >> 2
+    assert np.array_equal(half, ref.astype(np.uint8))
+    flat = np.full((33, 47, 3), 171, np.uint8)
+    assert np.all(oracle.resize_linear(flat, 91, 17) == 171)               # constant stays constant
+    up = oracle.resize_linear(img, 111, 160)
+    assert up.min() >= img.min() and up.max() <= img.max()                 # convex combination
+
+
+def test_preprocess_layout(oracle):
+    img = helpers.make_image(5, 90, 160)
+    det_img, tensor, sc = oracle.preprocess(img, 64, 64)
+    nw, nh, s2 = oracle.geometry(90, 160, 64, 64)
+    assert (nw, nh) == (64, 36) and sc == s2
+    assert np.all(det_img[nh:] == 0)                                       # zero canvas below the paste
+    assert np.array_equal(det_img[:nh, :nw], oracle.resize_linear(img, nh, nw))
+    assert np.array_equal(tensor, det_img[..., ::-1].transpose(2, 0, 1).astype(np.float32))  # BGR->RGB planes

@@ -1,0 +1,145 @@
+"""GPU parity tests of everything after the network: the HIP decode -> sort -> NMS -> rescale path
+(through the C ABI: rfd_decode_nms / rfd_nms_sorted / _nms) against the CPU oracle on the same
+seeded head tensors.  Bar: identical kept-anchor index sequences (bit-exact integer work) and
+box / landmark coordinates within 1e-4 (BASELINE.json north_star); scores bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def det640(rfd):
+    d = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=4, max_det=16800)
+    yield d
+    d.close()
+
+
+def _compare(oracle, det, heads, n, H, W, scales, conf=0.7, iou=0.45):
+    got = det.decode_nms(heads, scales, want_gidx=True)
+    exact = total = 0
+    for b in range(n):
+        hb = [h[b] for h in heads]
+        odet, olmk, ogidx, ncand = oracle.decode_nms(hb, H, W, conf, iou, det_scale=float(scales[b]))
+        gdet, glmk, ggidx = got[b]
+        assert np.array_equal(ggidx, ogidx), "kept index sequence differs (image %d)" % b
+        assert det.last_total[b] == len(ogidx)
+        assert np.array_equal(gdet[:, 4], odet[:, 4])
+        np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(glmk, olmk, rtol=0, atol=ATOL, equal_nan=True)
+        exact += int(np.sum(gdet == odet)) + int(np.sum((glmk == olmk) | (np.isnan(glmk) & np.isnan(olmk))))
+        total += gdet.size + glmk.size
+    return exact, total
+
+
+def test_typical(rfd, oracle, det640):
+    heads = helpers.make_heads(11, 4, cand_rate=0.006, n_faces=12)
+    sc = np.array([1.0, 1 / 3, 0.625, 0.99791664], np.float32)
+    exact, total = _compare(oracle, det640, heads, 4, 640, 640, sc)
+    assert exact == total  # in practice every coordinate is bit-identical, not merely within 1e-4
+    assert det640.stats()["candidates"] > 100
+
+
+def test_dense_crowd(rfd, oracle, det640):
+    # >500 clusters and thousands of candidates per image (BASELINE.json configs[4])
+    heads = helpers.make_heads(12, 2, cand_rate=0.2, n_faces=600)
+    exact, total = _compare(oracle, det640, heads, 2, 640, 640, np.array([1 / 6, 1 / 6], np.float32))
+    assert exact >= 0.9999 * total
+
+
+def test_worst_case_all_anchors(rfd, oracle, det640):
+    heads = helpers.make_heads(13, 1, cand_rate=1.0)
+    _compare(oracle, det640, heads, 1, 640, 640, np.array([1.0], np.float32))
+    assert det640.stats()["candidates"] == 16800
+
+
+def test_ties_follow_stable_sort_order(rfd, oracle, det640):
+    heads = helpers.make_heads(14, 2, cand_rate=0.05, n_faces=20, quantize=32)
+    _compare(oracle, det640, heads, 2, 640, 640, np.array([1.0, 0.5], np.float32))
+
+
+def test_empty(rfd, oracle, det640):
+    heads = helpers.make_heads(15, 2, cand_rate=0.0)
+    got = det640.decode_nms(heads, np.ones(2, np.float32))
+    for d, k in got:
+        assert d.shape == (0, 5) and k.shape == (0, 5, 2)   # face_detection.rs:413-419
+    assert det640.last_total.tolist() == [0, 0]
+
+
+def test_special_values(rfd, oracle, det640):
+    heads = helpers.make_heads(16, 1, cand_rate=0.3)
+    heads[0][0, 2:, :10] = np.nan          # NaN scores are filtered (`>=` is false)
+    heads[4][0, 2] = 100.0                 # exp overflow -> inf -> clipped
+    heads[4][0, 6] = -120.0                # exp underflow (subnormal / zero width)
+    heads[7][0, 0, 5:9] = np.nan           # NaN deltas: clip maps NaN to the upper bound
+    heads[8][0, 3, 2:4] = np.inf           # landmarks are not clipped
+    _compare(oracle, det640, heads, 1, 640, 640, np.array([0.5], np.float32))
+
+
+def test_thresholds_and_truncation(rfd, oracle):
+    d = rfd.RetinaFaceDetection(image_size=(320, 256), max_batch_size=2, max_det=7,
+                                confidence_threshold=0.5, iou_threshold=0.3)
+    heads = helpers.make_heads(17, 2, 256, 320, cand_rate=0.1, n_faces=5)
+    got = d.decode_nms(heads, np.ones(2, np.float32), want_gidx=True)
+    for b in range(2):
+        odet, olmk, ogidx, _ = oracle.decode_nms([h[b] for h in heads], 256, 320, 0.5, 0.3, 1.0)
+        assert d.last_total[b] == len(ogidx) and len(ogidx) > 7
+        assert np.array_equal(got[b][2], ogidx[:7])        # count = min(K, max_det), rows in kept order
+        np.testing.assert_allclose(got[b][0], odet[:7], rtol=0, atol=ATOL)
+    d.close()
+
+
+def test_golden_fixture(rfd):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads_128.npz"))
+    d = rfd.RetinaFaceDetection(image_size=(128, 128), max_batch_size=1, max_det=400)
+    heads = [z["h%d" % i][None] for i in range(9)]
+    (gdet, glmk, ggidx), = d.decode_nms(heads, np.array([z["det_scale"]], np.float32), want_gidx=True)
+    assert np.array_equal(ggidx, z["gidx"])
+    np.testing.assert_allclose(gdet, z["det"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(glmk, z["lmk"], rtol=0, atol=ATOL)
+    assert d.stats()["candidates"] == int(z["ncand"])
+    d.close()
+
+
+def test_nms_sorted_kat_and_random(rfd, oracle, det640):
+    boxes = np.array([[100, 100, 210, 210, .72], [250, 250, 420, 420, .8], [220, 220, 320, 330, .92],
+                      [100, 100, 210, 210, .6]], np.float32)          # src/processing/nms.rs:76-81
+    order = oracle.argsort_desc(boxes[:, 4])
+    keep = det640.nms_sorted(boxes[order], 0.4)
+    assert order[keep].tolist() == [2, 1, 0]
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 64, 65, 1000, 5000):
+        xy = rng.uniform(0, 600, size=(n, 2)); wh = rng.uniform(4, 150, size=(n, 2))
+        d = np.concatenate([xy, xy + wh, np.sort(rng.uniform(0, 1, size=(n, 1)), 0)[::-1]], 1).astype(np.float32)
+        assert np.array_equal(det640.nms_sorted(d, 0.45), oracle.nms(d, 0.45))
+    assert det640.nms_sorted(np.zeros((0, 5), np.float32), 0.45).size == 0
+
+
+def test_reference_nms_symbol(rfd, oracle):
+    """`_nms` keeps the reference's C signature (src/rcnn/gpu_nms.hpp:7)."""
+    L = rfd.load_library()
+    rng = np.random.default_rng(6)
+    n = 300
+    xy = rng.uniform(0, 300, size=(n, 2)); wh = rng.uniform(10, 90, size=(n, 2))
+    d = np.concatenate([xy, xy + wh, np.sort(rng.uniform(0, 1, size=(n, 1)), 0)[::-1]], 1).astype(np.float32)
+    keep = np.zeros(n, np.int32)
+    num = ctypes.c_int(0)
+    L._nms(keep.ctypes.data, ctypes.byref(num), d.ctypes.data, n, 5, 0.3, 0)
+    assert np.array_equal(keep[:num.value], oracle.nms(d, 0.3))
+
+
+def test_errors(rfd, det640):
+    heads = helpers.make_heads(18, 1)
+    with pytest.raises(rfd.RfdError) as e:
+        det640.decode_nms([h[:, :, :10] for h in heads], np.ones(1, np.float32))
+    assert e.value.status == rfd.RFD_ERR_INVALID_ARG
+    big = helpers.make_heads(19, 5, cand_rate=0.0)
+    with pytest.raises(rfd.RfdError) as e:
+        det640.decode_nms(big, np.ones(5, np.float32))
+    assert e.value.status == rfd.RFD_ERR_CAPACITY

@@ -1,0 +1,107 @@
+"""torch-CPU f32 reference executor for the build-defined network (test infrastructure).
+
+Walks the op list the library exposes (rfd_graph_*) and evaluates every op with torch functional
+ops on the SAME weights read back from the device, rounding activations to bf16 exactly where the
+HIP kernels do (every stored tensor except the f32 heads).  It is an independent implementation of
+the convolutions (torch/oneDNN), not the reference's network: the reference has none (the model
+lives on a Triton server that is not in the repo) -- CNN parity is "unpinned" (DESIGN.md)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class TorchRef:
+    def __init__(self, graph, det):
+        """graph: rfd_hip.Graph; det: rfd_hip.RetinaFaceDetection with initialised weights."""
+        self.g = graph
+        self.w, self.b, self.aff = [], [], []
+        for i, L in enumerate(graph.layers):
+            w, b = det.get_layer(i, L)
+            self.w.append(torch.from_numpy(w).permute(0, 3, 1, 2).contiguous())  # [cout][cin][kh][kw]
+            self.b.append(torch.from_numpy(b))
+            if L.has_affine:
+                s, t = det.get_affine(i, L.cout)
+                self.aff.append((torch.from_numpy(s), torch.from_numpy(t)))
+            else:
+                self.aff.append(None)
+
+    def run_op(self, i, tensors):
+        """tensors: dict id -> NCHW f32 torch tensor (bf16-rounded values).  Evaluates op i."""
+        g = self.g
+        o = g.ops[i]
+        L = g.layers[o.layer]
+        x = tensors[o.in_]
+        if o.kind == 0:  # conv0 7x7/2 on R,G,B (+ zero 4th channel) + bias + relu
+            v = F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
+            tensors[o.out] = bf16r(F.relu(v))
+            return
+        if o.kind == 1:  # maxpool 3x3/2 pad 1, then affine + relu
+            v = F.max_pool2d(x, 3, 2, 1)
+            s, t = self.aff[o.layer]
+            tensors[o.out] = bf16r(F.relu(v * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+            return
+        v = F.conv2d(x, self.w[o.layer], self.b[o.layer], stride=L.stride, padding=L.pad)
+        r = None
+        if o.res >= 0:
+            r = tensors[o.res]
+            if o.res_up2:
+                r = F.interpolate(r, scale_factor=2, mode="nearest")
+            if not o.res_post:
+                v = v + r
+        if o.out >= 0:
+            y = F.relu(v) if o.relu else v
+            if r is not None and o.res_post:
+                y = y + r
+            y = bf16r(y)
+            td = g.tensors[o.out]
+            if td.channels != L.cout:  # SSH concat: write a channel slice
+                if o.out not in tensors:
+                    tensors[o.out] = torch.zeros(x.shape[0], td.channels, td.height, td.width)
+                tensors[o.out][:, o.y_coff:o.y_coff + L.cout] = y
+            else:
+                tensors[o.out] = y
+        if o.out2 >= 0:
+            s, t = self.aff[o.layer]
+            tensors[o.out2] = bf16r(F.relu(v * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+        if o.outf >= 0:
+            if o.head_softmax:  # channels 0,1 = bg(a), 2,3 = fg(a): softmax over the pairs (a, A+a)
+                pr = torch.softmax(torch.stack([v[:, 0:2], v[:, 2:4]], 0), 0)
+                v = torch.cat([pr[0], pr[1], v[:, 4:]], 1)
+            tensors[o.outf] = v
+
+    def forward(self, x_nchw4, upto=None):
+        """x: [n,4,H,W] f32 (R,G,B,0).  Returns dict of all tensors (NCHW f32)."""
+        tensors = {next(i for i, t in enumerate(self.g.tensors) if t.is_input): x_nchw4}
+        last = len(self.g.ops) - 1 if upto is None else upto
+        with torch.no_grad():
+            for i in range(last + 1):
+                self.run_op(i, tensors)
+        return tensors
+
+    def heads(self, tensors):
+        """Head tensors in the reference's 9-tensor NCHW contract."""
+        out = []
+        for lvl in (1, 2, 3):
+            tid = next(i for i, t in enumerate(self.g.tensors) if t.head_level == lvl)
+            v = tensors[tid]
+            out += [v[:, 0:4].numpy().copy(), v[:, 4:12].numpy().copy(), v[:, 12:32].numpy().copy()]
+        return out
+
+
+def nchw_to_dev(t, is_f32=False):
+    """NCHW f32 torch tensor -> device layout (NHWC; bf16 bits as uint16, or f32)."""
+    a = t.permute(0, 2, 3, 1).contiguous()
+    if is_f32:
+        return a.numpy().astype(np.float32)
+    return a.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def dev_to_nchw(a, is_f32=False):
+    if is_f32:
+        return torch.from_numpy(a.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    t = torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).to(torch.float32)
+    return t.permute(0, 3, 1, 2).contiguous()
