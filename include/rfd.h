@@ -174,6 +174,10 @@ RFD_API int rfd_detect_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_det
  * unless `async` is non-zero (then call rfd_sync before reading results / reusing buffers). */
 RFD_API int rfd_detect_batch_device(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_dets *out, int async);
 RFD_API int rfd_sync(rfd_ctx *ctx);
+/* Enqueue on a caller-owned hipStream_t instead of the context's own stream (NULL restores it), so
+ * that a following collective (RCCL gather of the detection slabs) is stream-ordered behind the
+ * detector without a host synchronisation. */
+RFD_API int rfd_set_stream(rfd_ctx *ctx, void *hip_stream);
 
 /* ---- stage-level entry points (parity tests; each mirrors one reference stage) ---- */
 

@@ -101,6 +101,7 @@ using namespace rfd;
 struct rfd_ctx {
     rfd_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev[10] = {};
     float base_anchor[kNumLevels][kA][4];
     int fh[kNumLevels], fw[kNumLevels], level_off[kNumLevels], total_anchors = 0;
@@ -382,7 +383,8 @@ int rfd_create(const rfd_config *cfg, rfd_ctx **out)
     c->total_anchors = off;
     memset(&c->stats, 0, sizeof c->stats);
     int st = RFD_OK;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) st = RFD_ERR_HIP;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) st = RFD_ERR_HIP;
+    c->stream = c->own_stream;
     for (int i = 0; i < 10 && st == RFD_OK; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) st = RFD_ERR_HIP;
     for (int i = 0; i < rfd_ctx::kRing && st == RFD_OK; ++i) {
@@ -419,7 +421,7 @@ void rfd_destroy(rfd_ctx *c)
         if (c->pin_scales[i]) (void)hipHostFree(c->pin_scales[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -434,6 +436,14 @@ int rfd_get_stats(rfd_ctx *c, rfd_stats *stats)
 {
     RFD_CHECK_ARG(c && stats, "null argument");
     *stats = c->stats;
+    return RFD_OK;
+}
+
+int rfd_set_stream(rfd_ctx *c, void *hip_stream)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RFD_OK;
 }
 

@@ -71,6 +71,7 @@ struct ConvParams {
     const bf16_t *x;      // [B][H][W][Cin]
     const bf16_t *w;      // [Cout][KH*KW*Cin]
     const float *bias;    // [Cout] (BN folded)
+    const bf16_t *zero;   // >= 16 bytes of zeros (source of padding taps for the LDS-DMA)
     const bf16_t *res;    // residual [B][RH][RW][Cout] or null; added before relu / raw store
     const float *scale2;  // second output: act = relu(v * scale2 + shift2), or null
     const float *shift2;

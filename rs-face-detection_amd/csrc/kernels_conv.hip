@@ -6,11 +6,15 @@
 // The weight tile is the MFMA A operand and the im2col activation tile the B operand, so every lane
 // ends up with 4 consecutive output CHANNELS of one pixel -> packed 8-byte NHWC stores.
 //
-// Per workgroup (256 threads = 4 wave64): BM x BN output tile, K step 64, both operand tiles
-// staged global -> VGPR -> LDS (XOR-swizzled 128-byte rows: conflict-free ds_read_b128 fragments),
-// double-buffered, one barrier per K step; v_mfma_f32_16x16x32_bf16 with f32 accumulators;
-// epilogue fused: +bias (BN folded), +residual (optionally nearest-2x upsampled), ReLU, second
-// "BN+ReLU" output for pre-activation units, channel-offset stores (SSH concat), f32 + softmax heads.
+// Per workgroup (256 threads = 4 wave64): BM x BN output tile, K step 64.  Both operand tiles go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write), double
+// buffered, one barrier per K step; the LDS image is lane-linear, so the XOR swizzle that makes the
+// ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address (and to the
+// read); padding taps and rows beyond M read a zero page.  v_mfma_f32_16x16x32_bf16, f32 accumulate.
+// Epilogue: accumulators are transposed through LDS so that every global access is a 16-byte,
+// channel-contiguous piece of a full 128-byte line; fused: +bias (BN folded), +residual (optionally
+// nearest-2x upsampled), ReLU, second "BN+ReLU" output for pre-activation units, channel-offset
+// stores (SSH concat), f32 + 2-class softmax for the heads.
 #include "kernels.h"
 
 namespace rfd {
@@ -35,21 +39,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// LDS-DMA: one wave instruction moves 64 x 16 B straight from global memory into LDS at
+// (wave-uniform base) + lane*16; the per-lane SOURCE address carries the swizzle.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
-    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int NT = WAVES_M * WAVES_N * 64, NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int ROWS_PER_PASS = NT / 8;          // 8 x 16-byte chunks per 64-wide K row
-    constexpr int XL = BM / ROWS_PER_PASS, WL = BN / ROWS_PER_PASS;
-    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/thread mismatch");
+    // staging: one DMA instruction = 8 rows x 128 B; wave w issues pieces w, w+NW, ...
+    constexpr int XP = BM / 8 / NW, WP = (BN / 8 + NW - 1) / NW;
+    static_assert((BM / 8) % NW == 0, "X tile pieces must divide over the waves");
+    constexpr int CP = BN + 4; // f32 pitch of the epilogue staging tile (conflict-free b128 writes)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [2][BM*64]
     bf16_t *Ws = Xs + 2 * BM * 64;                             // [2][BN*64]
+    float *Cs = reinterpret_cast<float *>(smem);               // [BM][CP] (epilogue, aliases the operands)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
@@ -58,55 +73,50 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
-    // ---- per-thread im2col row bookkeeping (rows tid/8 + ROWS_PER_PASS*i, chunk tid%8) ----
-    const int c8 = tid & 7, r0 = tid >> 3;
-    long long xoff[XL];
-    int hi0[XL], wi0[XL];
+    // ---- per-lane im2col bookkeeping: lane (r = lane/8, slot = lane%8) of piece q stages LDS row
+    //      R = (wave + NW*q)*8 + r, slot `slot`, which holds global chunk slot ^ r of that row ----
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr;
+    long long xoff[XP];
+    int hi0[XP], wi0[XP];
 #pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int m = m0 + r0 + ROWS_PER_PASS * i;
+    for (int q = 0; q < XP; ++q) {
+        const int m = m0 + (wave + NW * q) * 8 + lr;
         if (m < M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            hi0[i] = ho * p.stride - p.pad;
-            wi0[i] = wo * p.stride - p.pad;
-            xoff[i] = (((long long)b * p.H + hi0[i]) * p.W + wi0[i]) * p.Cin + c8 * 8;
+            hi0[q] = ho * p.stride - p.pad;
+            wi0[q] = wo * p.stride - p.pad;
+            xoff[q] = (((long long)b * p.H + hi0[q]) * p.W + wi0[q]) * p.Cin + chunk * 8;
         } else {
-            hi0[i] = -(1 << 28); // fails every bounds check -> zero rows
-            wi0[i] = 0;
-            xoff[i] = 0;
+            hi0[q] = -(1 << 28); // fails every bounds check -> zero rows
+            wi0[q] = 0;
+            xoff[q] = 0;
         }
     }
-    const bf16_t *wrow = p.w + (size_t)(n0 + r0) * K + c8 * 8;
+    const bf16_t *wsrc[WP];
+#pragma unroll
+    for (int q = 0; q < WP; ++q) {
+        const int piece = wave + NW * q;
+        wsrc[q] = p.w + (size_t)(n0 + (piece < BN / 8 ? piece * 8 + lr : 0)) * K + chunk * 8;
+    }
 
-    uint4 xr[XL], wr[WL];
-    int ky = 0, kx = 0, kc = 0; // position of the NEXT tile to load
+    int ky = 0, kx = 0, kc = 0, kt_load = 0; // position of the NEXT tile to stage
     const int kc_n = p.Cin >> 6;
-    int kt_load = 0;
-    auto load_tile = [&]() {
+    auto stage = [&](int buf) {
         const long long tap = ((long long)ky * p.W + kx) * p.Cin + (kc << 6);
 #pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const bool ok = (unsigned)(hi0[i] + ky) < (unsigned)p.H && (unsigned)(wi0[i] + kx) < (unsigned)p.W;
-            xr[i] = ok ? *reinterpret_cast<const uint4 *>(p.x + xoff[i] + tap) : make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < XP; ++q) {
+            const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
+            const bf16_t *src = ok ? p.x + xoff[q] + tap : p.zero;
+            glds16(src, Xs + buf * BM * 64 + (wave + NW * q) * 512);
         }
 #pragma unroll
-        for (int i = 0; i < WL; ++i)
-            wr[i] = *reinterpret_cast<const uint4 *>(wrow + (size_t)(ROWS_PER_PASS * i) * K + (kt_load << 6));
+        for (int q = 0; q < WP; ++q) {
+            const int piece = wave + NW * q;
+            if (piece < BN / 8) glds16(wsrc[q] + (kt_load << 6), Ws + buf * BN * 64 + piece * 512);
+        }
         ++kt_load;
         if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int r = r0 + ROWS_PER_PASS * i;
-            *reinterpret_cast<uint4 *>(Xs + buf * BM * 64 + r * 64 + ((c8 ^ (r & 7)) << 3)) = xr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WL; ++i) {
-            const int r = r0 + ROWS_PER_PASS * i;
-            *reinterpret_cast<uint4 *>(Ws + buf * BN * 64 + r * 64 + ((c8 ^ (r & 7)) << 3)) = wr[i];
-        }
     };
 
     f32x4 acc[TN][TM];
@@ -116,14 +126,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K >> 6;
-    load_tile();
-    store_tile(0);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(); // global loads in flight under the MFMAs below
+        if (kt + 1 < nk) stage(buf ^ 1); // DMA of the next tile runs under the MFMAs below
         const bf16_t *xs = Xs + buf * BM * 64 + (wm * WM) * 64;
         const bf16_t *ws = Ws + buf * BN * 64 + (wn * WN) * 64;
 #pragma unroll
@@ -132,7 +142,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
             const int ch = kk * 4 + fq;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const int r = i * 16 + frow; // (wn*WN) is a multiple of 16, so (row & 7) == (r & 7)
+                const int r = i * 16 + frow;
                 af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3));
             }
 #pragma unroll
@@ -146,58 +156,90 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged tile has landed
+        __syncthreads();                                   // ... for every wave; and `buf` is free again
     }
 
-    // ---- fused epilogue: lane holds channels n..n+3 of pixel m ----
+    // ---- epilogue: accumulators -> LDS (f32, transposed to pixel-major) -> fused math -> 16-byte
+    //      channel-contiguous global accesses (full 128-byte lines) ----
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WM + j * 16 + frow;
-        if (m >= M) continue;
-        size_t mr = (size_t)m;
-        if (p.res && p.res_up2) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            *reinterpret_cast<f32x4 *>(Cs + (wm * WM + j * 16 + frow) * CP + wn * WN + i * 16 + fq * 4) = acc[i][j];
+    __syncthreads();
+
+    constexpr int CH = BN / 8;           // 8-channel (16-byte bf16) chunks per tile row
+    constexpr int RPP = NT / CH;         // rows per pass
+    const int col8 = tid % CH, rsub = tid / CH;
+    const int n = n0 + col8 * 8;
+    float bias[8], s2[8], t2[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+    if (p.y2) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
+        const float4 c0 = *reinterpret_cast<const float4 *>(p.shift2 + n), c1 = *reinterpret_cast<const float4 *>(p.shift2 + n + 4);
+        s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
+        t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
+    }
+#pragma unroll 2
+    for (int row = rsub; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= M) break;
+        const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * CP + col8 * 8);
+        const float4 c1 = *reinterpret_cast<const float4 *>(Cs + row * CP + col8 * 8 + 4);
+        float v[8] = {c0.x + bias[0], c0.y + bias[1], c0.z + bias[2], c0.w + bias[3],
+                      c1.x + bias[4], c1.y + bias[5], c1.z + bias[6], c1.w + bias[7]};
+        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+            size_t mr = (size_t)m;
+            if (p.res_up2) {
+                const int b = m / HoWo, rem = m - b * HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+            }
+            const uint4 rv = *reinterpret_cast<const uint4 *>(p.res + mr * p.Cout + n);
+            r[0] = bf16_bits_to_f32(rv.x & 0xffffu); r[1] = bf16_bits_to_f32(rv.x >> 16);
+            r[2] = bf16_bits_to_f32(rv.y & 0xffffu); r[3] = bf16_bits_to_f32(rv.y >> 16);
+            r[4] = bf16_bits_to_f32(rv.z & 0xffffu); r[5] = bf16_bits_to_f32(rv.z >> 16);
+            r[6] = bf16_bits_to_f32(rv.w & 0xffffu); r[7] = bf16_bits_to_f32(rv.w >> 16);
+            if (!p.res_post) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += r[k];
+            }
         }
+        if (p.y) {
+            float o[8];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * WN + i * 16 + fq * 4;
-            const float4 bias = *reinterpret_cast<const float4 *>(p.bias + n);
-            float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y;
-            float v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
-            float r0f = 0.f, r1f = 0.f, r2f = 0.f, r3f = 0.f;
-            if (p.res) {
-                const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + mr * p.Cout + n);
-                r0f = bf16_bits_to_f32(rv.x & 0xffffu); r1f = bf16_bits_to_f32(rv.x >> 16);
-                r2f = bf16_bits_to_f32(rv.y & 0xffffu); r3f = bf16_bits_to_f32(rv.y >> 16);
-                if (!p.res_post) { v0 += r0f; v1 += r1f; v2 += r2f; v3 += r3f; }
+            for (int k = 0; k < 8; ++k) {
+                o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
+                if (p.res && p.res_post) o[k] += r[k];
             }
-            if (p.y) {
-                float o0 = v0, o1 = v1, o2 = v2, o3 = v3;
-                if (p.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
-                if (p.res && p.res_post) { o0 += r0f; o1 += r1f; o2 += r2f; o3 += r3f; }
-                *reinterpret_cast<uint2 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = pack_bf16x4(o0, o1, o2, o3);
+            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+            *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        if (p.y2) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
+            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+            *reinterpret_cast<uint4 *>(p.y2 + (size_t)m * p.Cout + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        if (p.yf) {
+            if (p.head_softmax && n == 0) {
+                // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
+                const float m0s = fmaxf(v[0], v[2]), m1s = fmaxf(v[1], v[3]);
+                const float e0 = expf(v[0] - m0s), e2 = expf(v[2] - m0s);
+                const float e1 = expf(v[1] - m1s), e3 = expf(v[3] - m1s);
+                v[0] = e0 / (e0 + e2); v[2] = e2 / (e0 + e2);
+                v[1] = e1 / (e1 + e3); v[3] = e3 / (e1 + e3);
             }
-            if (p.y2) {
-                const float4 s2 = *reinterpret_cast<const float4 *>(p.scale2 + n);
-                const float4 t2 = *reinterpret_cast<const float4 *>(p.shift2 + n);
-                *reinterpret_cast<uint2 *>(p.y2 + (size_t)m * p.Cout + n) =
-                    pack_bf16x4(fmaxf(v0 * s2.x + t2.x, 0.f), fmaxf(v1 * s2.y + t2.y, 0.f),
-                                fmaxf(v2 * s2.z + t2.z, 0.f), fmaxf(v3 * s2.w + t2.w, 0.f));
-            }
-            if (p.yf) {
-                if (p.head_softmax && n == 0) {
-                    // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
-                    const float m0s = fmaxf(v0, v2), m1s = fmaxf(v1, v3);
-                    const float e0 = expf(v0 - m0s), e2 = expf(v2 - m0s);
-                    const float e1 = expf(v1 - m1s), e3 = expf(v3 - m1s);
-                    v0 = e0 / (e0 + e2); v2 = e2 / (e0 + e2);
-                    v1 = e1 / (e1 + e3); v3 = e3 / (e1 + e3);
-                }
-                *reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n) = make_float4(v0, v1, v2, v3);
-            }
+            float4 *dst = reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
         }
     }
 }
@@ -207,7 +249,7 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int grid = ceil_div(M, BM) * (p.Cout / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
+    const size_t lds = std::max((size_t)2 * (BM + BN) * 64 * sizeof(bf16_t), (size_t)BM * (BN + 4) * sizeof(float));
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -222,8 +264,8 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 
 int launch_conv(const ConvParams &p, hipStream_t s)
 {
-    if (p.Cin % 64 != 0 || p.Cout % 32 != 0) {
-        set_error("conv: Cin=%d must be a multiple of 64 and Cout=%d of 32", p.Cin, p.Cout);
+    if (p.Cin % 64 != 0 || p.Cout % 32 != 0 || !p.zero) {
+        set_error("conv: Cin=%d must be a multiple of 64, Cout=%d of 32, and a zero page is required", p.Cin, p.Cout);
         return RFD_ERR_INVALID_ARG;
     }
     if (p.Cout % 128 == 0) return launch_conv_cfg<128, 128, 2, 2>(p, s);

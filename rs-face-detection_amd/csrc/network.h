@@ -65,6 +65,7 @@ struct Network {
     bool weights_ready = false;
     bf16_t *d_w = nullptr;
     float *d_b = nullptr;
+    bf16_t *d_zero = nullptr;
     std::vector<void *> d_buffers;
     bool profiling = false;
     std::vector<hipEvent_t> ev; // 2 per op when profiling

@@ -240,6 +240,8 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     max_batch = max_batch_;
     RFD_HIP(hipMalloc((void **)&d_w, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMalloc((void **)&d_b, g.b_total * sizeof(float)));
+    RFD_HIP(hipMalloc((void **)&d_zero, 256));
+    RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
     for (size_t i = 0; i < d_buffers.size(); ++i)
         RFD_HIP(hipMalloc(&d_buffers[i], g.buffer_bytes_per_image[i] * (size_t)max_batch));
@@ -250,6 +252,8 @@ void Network::destroy()
 {
     if (d_w) (void)hipFree(d_w);
     if (d_b) (void)hipFree(d_b);
+    if (d_zero) (void)hipFree(d_zero);
+    d_zero = nullptr;
     for (void *p : d_buffers)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
@@ -422,6 +426,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
             p.x = (const bf16_t *)tensor_ptr(o.in);
             p.w = d_w + L.w_off;
             p.bias = d_b + L.b_off;
+            p.zero = d_zero;
             p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
             p.scale2 = d_b + L.b_off + L.cout;
             p.shift2 = d_b + L.b_off + 2 * L.cout;

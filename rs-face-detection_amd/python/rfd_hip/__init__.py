@@ -86,7 +86,7 @@ API_SYMBOLS = [
     "rfd_graph_tensor", "rfd_graph_macs", "rfd_graph_workspace_bytes",
     "rfd_init_synthetic_weights", "rfd_num_layers", "rfd_get_layer_weights",
     "rfd_set_layer_weights", "rfd_get_layer_affine", "rfd_set_layer_affine", "rfd_detect_batch",
-    "rfd_detect_batch_device", "rfd_sync", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
+    "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
     "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops",
 ]
@@ -131,6 +131,7 @@ def load_library(path=None):
     L.rfd_detect_batch.argtypes = [vp, C.POINTER(rfd_image), ci, C.POINTER(rfd_dets)]
     L.rfd_detect_batch_device.argtypes = [vp, C.POINTER(rfd_image), ci, C.POINTER(rfd_dets), ci]
     L.rfd_sync.argtypes = [vp]
+    L.rfd_set_stream.argtypes = [vp, vp]
     L.rfd_preprocess.argtypes = [vp, C.POINTER(rfd_image), ci, vp, vp, vp]
     L.rfd_forward.argtypes = [vp, vp, ci, C.POINTER(vp)]
     L.rfd_decode_nms.argtypes = [vp, C.POINTER(vp), ci, vp, C.POINTER(rfd_dets), vp]
@@ -324,6 +325,10 @@ class RetinaFaceDetection:
 
     def sync(self):
         _check(self._L.rfd_sync(self._ctx))
+
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None restores."""
+        _check(self._L.rfd_set_stream(self._ctx, hip_stream))
 
     # ---- stage-level entry points ----
     def preprocess(self, frames):
