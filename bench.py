@@ -24,7 +24,7 @@ for p in (ROOT, os.path.join(ROOT, "rs-face-detection_amd", "python"), os.path.j
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-BATCH = 32
+BATCH = int(os.environ.get("RFD_BENCH_BATCH", "32"))  # 32 is the headline configuration
 IMAGE = 640
 MAX_DET = 1024
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md

@@ -11,10 +11,12 @@
 // buffered, one barrier per K step; the LDS image is lane-linear, so the XOR swizzle that makes the
 // ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address (and to the
 // read); padding taps and rows beyond M read a zero page.  v_mfma_f32_16x16x32_bf16, f32 accumulate.
-// Epilogue: accumulators are transposed through LDS so that every global access is a 16-byte,
-// channel-contiguous piece of a full 128-byte line; fused: +bias (BN folded), +residual (optionally
-// nearest-2x upsampled), ReLU, second "BN+ReLU" output for pre-activation units, channel-offset
-// stores (SSH concat), f32 + 2-class softmax for the heads.
+// Epilogue straight from the accumulators: the weight-tile ROWS are permuted when staged so that the
+// 2 x 4 accumulator registers a lane holds for an MFMA row-tile pair are 8 CONSECUTIVE output
+// channels of one pixel -> one 16-byte store per lane, 64 contiguous bytes per pixel per instruction,
+// no LDS round trip; the residual is prefetched before the K loop in the same layout.  Fused: +bias
+// (BN folded), +residual (optionally nearest-2x upsampled), ReLU, second "BN+ReLU" output for
+// pre-activation units, channel-offset stores (SSH concat), f32 + 2-class softmax for the heads.
 #include "kernels.h"
 
 namespace rfd {
@@ -56,12 +58,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     // staging: one DMA instruction = 8 rows x 128 B; wave w issues pieces w, w+NW, ...
     constexpr int XP = BM / 8 / NW, WP = (BN / 8 + NW - 1) / NW;
     static_assert((BM / 8) % NW == 0, "X tile pieces must divide over the waves");
-    constexpr int CP = BN + 4; // f32 pitch of the epilogue staging tile (conflict-free b128 writes)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [2][BM*64]
-    bf16_t *Ws = Xs + 2 * BM * 64;                             // [2][BN*64]
-    float *Cs = reinterpret_cast<float *>(smem);               // [BM][CP] (epilogue, aliases the operands)
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [nbuf][BM*64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +68,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
     const int K = p.KH * p.KW * p.Cin;
+    const int nk = K >> 6;
+    bf16_t *Ws = Xs + (nk > 1 ? 2 : 1) * BM * 64;              // [nbuf][BN*64]; nbuf = 1 for a single K step
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
@@ -97,7 +98,12 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
     for (int q = 0; q < WP; ++q) {
         const int piece = wave + NW * q;
-        wsrc[q] = p.w + (size_t)(n0 + (piece < BN / 8 ? piece * 8 + lr : 0)) * K + chunk * 8;
+        // LDS row rho = i*16 + fq*4 + r (the MFMA A-operand row) holds output channel
+        // (i>>1)*32 + fq*8 + (i&1)*4 + r of the wave's WN-wide slice
+        const int rho = (piece < BN / 8 ? piece * 8 + lr : 0);
+        const int rw = rho % WN, i_ = rw >> 4, fq_ = (rw >> 2) & 3, r_ = rw & 3;
+        const int chn = (rho - rw) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        wsrc[q] = p.w + (size_t)(n0 + chn) * K + chunk * 8;
     }
 
     int ky = 0, kx = 0, kc = 0, kt_load = 0; // position of the NEXT tile to stage
@@ -125,12 +131,30 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int TH = TN / 2; // 8-channel groups per lane and pixel
+    // residual prefetch (independent of the GEMM): 16 bytes = the lane's 8 channels of pixel (j)
+    uint4 resv[TM][TH];
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 16 + frow;
+            size_t mr = (size_t)(m < M ? m : 0);
+            if (p.res_up2 && m < M) {
+                const int b = m / HoWo, rem = m - b * HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+            }
+#pragma unroll
+            for (int h = 0; h < TH; ++h)
+                resv[j][h] = *reinterpret_cast<const uint4 *>(p.res + mr * p.Cout + n0 + wn * WN + h * 32 + fq * 8);
+        }
+    }
+
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int frow = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(buf ^ 1); // DMA of the next tile runs under the MFMAs below
@@ -156,90 +180,80 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged tile has landed
-        __syncthreads();                                   // ... for every wave; and `buf` is free again
-    }
-
-    // ---- epilogue: accumulators -> LDS (f32, transposed to pixel-major) -> fused math -> 16-byte
-    //      channel-contiguous global accesses (full 128-byte lines) ----
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-            *reinterpret_cast<f32x4 *>(Cs + (wm * WM + j * 16 + frow) * CP + wn * WN + i * 16 + fq * 4) = acc[i][j];
-    __syncthreads();
-
-    constexpr int CH = BN / 8;           // 8-channel (16-byte bf16) chunks per tile row
-    constexpr int RPP = NT / CH;         // rows per pass
-    const int col8 = tid % CH, rsub = tid / CH;
-    const int n = n0 + col8 * 8;
-    float bias[8], s2[8], t2[8];
-    {
-        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
-        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
-        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-    }
-    if (p.y2) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
-        const float4 c0 = *reinterpret_cast<const float4 *>(p.shift2 + n), c1 = *reinterpret_cast<const float4 *>(p.shift2 + n + 4);
-        s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
-        t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
-    }
-#pragma unroll 2
-    for (int row = rsub; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= M) break;
-        const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * CP + col8 * 8);
-        const float4 c1 = *reinterpret_cast<const float4 *>(Cs + row * CP + col8 * 8 + 4);
-        float v[8] = {c0.x + bias[0], c0.y + bias[1], c0.z + bias[2], c0.w + bias[3],
-                      c1.x + bias[4], c1.y + bias[5], c1.z + bias[6], c1.w + bias[7]};
-        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (p.res) {
-            size_t mr = (size_t)m;
-            if (p.res_up2) {
-                const int b = m / HoWo, rem = m - b * HoWo;
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
-            }
-            const uint4 rv = *reinterpret_cast<const uint4 *>(p.res + mr * p.Cout + n);
-            r[0] = bf16_bits_to_f32(rv.x & 0xffffu); r[1] = bf16_bits_to_f32(rv.x >> 16);
-            r[2] = bf16_bits_to_f32(rv.y & 0xffffu); r[3] = bf16_bits_to_f32(rv.y >> 16);
-            r[4] = bf16_bits_to_f32(rv.z & 0xffffu); r[5] = bf16_bits_to_f32(rv.z >> 16);
-            r[6] = bf16_bits_to_f32(rv.w & 0xffffu); r[7] = bf16_bits_to_f32(rv.w >> 16);
-            if (!p.res_post) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += r[k];
-            }
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged tile has landed
+            __syncthreads();                                   // ... for every wave; and `buf` is free again
         }
-        if (p.y) {
-            float o[8];
+    }
+
+    // ---- fused epilogue from registers: lane = pixel (j*16 + frow), channels h*32 + fq*8 .. +7 ----
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
-                if (p.res && p.res_post) o[k] += r[k];
-            }
-            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-            *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    for (int h = 0; h < TH; ++h) {
+        const int n = n0 + wn * WN + h * 32 + fq * 8;
+        float bias[8], s2[8], t2[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
         }
         if (p.y2) {
-            float o[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
-            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-            *reinterpret_cast<uint4 *>(p.y2 + (size_t)m * p.Cout + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(p.shift2 + n), c1 = *reinterpret_cast<const float4 *>(p.shift2 + n + 4);
+            s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
+            t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
         }
-        if (p.yf) {
-            if (p.head_softmax && n == 0) {
-                // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
-                const float m0s = fmaxf(v[0], v[2]), m1s = fmaxf(v[1], v[3]);
-                const float e0 = expf(v[0] - m0s), e2 = expf(v[2] - m0s);
-                const float e1 = expf(v[1] - m1s), e3 = expf(v[3] - m1s);
-                v[0] = e0 / (e0 + e2); v[2] = e2 / (e0 + e2);
-                v[1] = e1 / (e1 + e3); v[3] = e3 / (e1 + e3);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 16 + frow;
+            if (m >= M) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = acc[2 * h][j][k] + bias[k];
+                v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k];
             }
-            float4 *dst = reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n);
-            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                const uint4 rv = resv[j][h];
+                r[0] = bf16_bits_to_f32(rv.x & 0xffffu); r[1] = bf16_bits_to_f32(rv.x >> 16);
+                r[2] = bf16_bits_to_f32(rv.y & 0xffffu); r[3] = bf16_bits_to_f32(rv.y >> 16);
+                r[4] = bf16_bits_to_f32(rv.z & 0xffffu); r[5] = bf16_bits_to_f32(rv.z >> 16);
+                r[6] = bf16_bits_to_f32(rv.w & 0xffffu); r[7] = bf16_bits_to_f32(rv.w >> 16);
+                if (!p.res_post) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += r[k];
+                }
+            }
+            if (p.y) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
+                    if (p.res && p.res_post) o[k] += r[k];
+                }
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            if (p.y2) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                *reinterpret_cast<uint4 *>(p.y2 + (size_t)m * p.Cout + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            if (p.yf) {
+                if (p.head_softmax && n == 0) {
+                    // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
+                    const float m0s = fmaxf(v[0], v[2]), m1s = fmaxf(v[1], v[3]);
+                    const float e0 = expf(v[0] - m0s), e2 = expf(v[2] - m0s);
+                    const float e1 = expf(v[1] - m1s), e3 = expf(v[3] - m1s);
+                    v[0] = e0 / (e0 + e2); v[2] = e2 / (e0 + e2);
+                    v[1] = e1 / (e1 + e3); v[3] = e3 / (e1 + e3);
+                }
+                float4 *dst = reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n);
+                dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
         }
     }
 }
@@ -249,12 +263,13 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int grid = ceil_div(M, BM) * (p.Cout / BN);
-    const size_t lds = std::max((size_t)2 * (BM + BN) * 64 * sizeof(bf16_t), (size_t)BM * (BN + 4) * sizeof(float));
+    const int nk = p.KH * p.KW * p.Cin / 64;
+    const size_t lds = (size_t)(nk > 1 ? 2 : 1) * (BM + BN) * 64 * sizeof(bf16_t); // single K step: one buffer, more blocks per CU
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
         RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * 64 * sizeof(bf16_t))));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
