@@ -137,7 +137,9 @@ typedef struct rfd_op_desc {
                                      outf = f32 result (heads), res = residual input */
     int relu, res_up2, res_post, head_softmax, y_coff;
     double macs; /* multiply-accumulates per image */
-    int reserved[4];
+    int in2, layer2; /* fused 1x1 shortcut conv: + conv(tensor in2, layer2) (+ its bias); -1 = none */
+    int in_affine;   /* >= 0: the input is first mapped through relu(x*scale+shift) of that layer's affine */
+    int reserved[1];
 } rfd_op_desc;
 typedef struct rfd_tensor_desc {
     int channels, height, width;
@@ -230,6 +232,8 @@ RFD_API int rfd_get_op_profile(rfd_ctx *ctx, float *ms, int cap);
  *      op list [first_op, last_op] (last_op < 0: to the end), so every op can be checked in isolation. */
 RFD_API int rfd_debug_tensor_io(rfd_ctx *ctx, int tensor_id, int n, void *host, int write);
 RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
+/* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal */
+RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
 
 #ifdef __cplusplus
 }

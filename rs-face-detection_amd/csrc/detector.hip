@@ -524,6 +524,7 @@ int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
     d->kind = o.kind; d->layer = o.layer; d->in = o.in; d->out = o.out; d->out2 = o.out2; d->outf = o.outf;
     d->res = o.res; d->relu = o.relu; d->res_up2 = o.res_up2; d->res_post = o.res_post;
     d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
+    d->in2 = o.in2; d->layer2 = o.layer2; d->in_affine = o.in_affine;
     d->macs = g->layer_macs(idx);
     return RFD_OK;
 }
@@ -564,6 +565,13 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
     if (write) RFD_HIP(hipMemcpyAsync(c->net.tensor_ptr(tensor_id), host, bytes, hipMemcpyHostToDevice, c->stream));
     else RFD_HIP(hipMemcpyAsync(host, c->net.tensor_ptr(tensor_id), bytes, hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+int rfd_debug_set_conv_tile(rfd_ctx *c, int tile)
+{
+    RFD_CHECK_ARG(c && tile >= 0 && tile <= 2, "bad argument");
+    RFD_TRY(c->ensure_network());
+    c->net.force_tile = tile;
     return RFD_OK;
 }
 int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)

@@ -69,20 +69,26 @@ int launch_nms(NmsParams p, int n_images, hipStream_t s);
 // Activations: NHWC bf16.  Weights: [Cout][KH][KW][Cin] bf16 (K contiguous).  f32 accumulate on MFMA.
 struct ConvParams {
     const bf16_t *x;      // [B][H][W][Cin]
-    const bf16_t *w;      // [Cout][KH*KW*Cin]
+    const bf16_t *w;      // [Cout][KH*KW*Cin (+ Cin2)]: row pitch = total K
+    const bf16_t *x2;     // optional second K segment: a 1x1 conv (stride2, no pad) over [B][H2][W2][Cin2]
+    const float *bias2;   // its bias (added to `bias`), or null
     const float *bias;    // [Cout] (BN folded)
     const bf16_t *zero;   // >= 16 bytes of zeros (source of padding taps for the LDS-DMA)
     const bf16_t *res;    // residual [B][RH][RW][Cout] or null; added before relu / raw store
+    const float *in_scale; // optional per-INPUT-channel affine + ReLU applied to the im2col operand (1x1 convs
+    const float *in_shift; // only): x' = relu(x * in_scale[c] + in_shift[c]) -- the BN+ReLU of the producer unit
     const float *scale2;  // second output: act = relu(v * scale2 + shift2), or null
     const float *shift2;
     bf16_t *y;            // primary output [B][Ho][Wo][ldy] at channel offset y_coff (null: skip)
     bf16_t *y2;           // activated second output [B][Ho][Wo][Cout] or null
     float *yf;            // f32 output [B][Ho][Wo][Cout] (heads) or null
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int H2, W2, Cin2, stride2;
     int ldy, y_coff;      // primary output row pitch (channels) and channel offset (SSH concat)
     int relu;             // relu on the primary output
     int res_up2;          // residual is half resolution: read at (ho/2, wo/2) (FPN nearest 2x)
     int res_post;         // add the residual AFTER the ReLU (FPN: relu(lateral) + upsampled)
+    int force_tile;       // 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tile (tuning / tests)
     int head_softmax;     // heads: channels [0,4) are cls logits -> 2-class softmax pairs (a, A+a)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);

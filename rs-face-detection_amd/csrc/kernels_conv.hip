@@ -10,7 +10,7 @@
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write), double
 // buffered, one barrier per K step; the LDS image is lane-linear, so the XOR swizzle that makes the
 // ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address (and to the
-// read); padding taps and rows beyond M read a zero page.  v_mfma_f32_16x16x32_bf16, f32 accumulate.
+// read); padding taps and rows beyond M use an out-of-range buffer offset, which reads as zeros.  v_mfma_f32_16x16x32_bf16, f32 accumulate.
 // Epilogue straight from the accumulators: the weight-tile ROWS are permuted when staged so that the
 // 2 x 4 accumulator registers a lane holds for an MFMA row-tile pair are 8 CONSECUTIVE output
 // channels of one pixel -> one 16-byte store per lane, 64 contiguous bytes per pixel per instruction,
@@ -43,13 +43,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // LDS-DMA: one wave instruction moves 64 x 16 B straight from global memory into LDS at
 // (wave-uniform base) + lane*16; the per-lane SOURCE address carries the swizzle.
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base)
+// Buffer form (buffer_load_dwordx4 ... offen lds): 32-bit per-lane byte offset + scalar offset, and the
+// hardware range check returns ZEROS for a per-lane offset >= num_records -- conv padding for free.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, uint32_t soffset,
+                                       void *lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16,
+                                             voffset, soffset, 0, 0);
+}
+constexpr uint32_t kOob = 0xfffffff0u; // >= any num_records: reads as zeros, touches no memory
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// NS = slots of the LDS operand ring: NS - 1 K-tiles are in flight (LDS-DMA) or being consumed while
+// one is free; a counted s_waitcnt vmcnt leaves the younger tiles in flight across the barrier.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = WAVES_M * WAVES_N;
@@ -60,66 +71,84 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     static_assert((BM / 8) % NW == 0, "X tile pieces must divide over the waves");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [nbuf][BM*64]
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);             // [slots][BM*64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
-    const int K = p.KH * p.KW * p.Cin;
-    const int nk = K >> 6;
-    bf16_t *Ws = Xs + (nk > 1 ? 2 : 1) * BM * 64;              // [nbuf][BN*64]; nbuf = 1 for a single K step
+    const int K1 = p.KH * p.KW * p.Cin;
+    const int K = K1 + p.Cin2; // second K segment: the fused 1x1 shortcut conv
+    const int nk1 = K1 >> 6, nk = K >> 6;
+    bf16_t *Ws = Xs + (nk > 1 ? NS : 1) * BM * 64;             // [slots][BN*64]; one slot for a single K step
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
     // ---- per-lane im2col bookkeeping: lane (r = lane/8, slot = lane%8) of piece q stages LDS row
-    //      R = (wave + NW*q)*8 + r, slot `slot`, which holds global chunk slot ^ r of that row ----
+    //      R = (wave + NW*q)*8 + r, slot `slot`, which holds global chunk slot ^ r of that row.
+    //      Offsets are BYTES relative to the tensor base (32-bit: tensors are < 4 GiB). ----
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr;
-    long long xoff[XP];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.Cin2 ? p.x2 : p.x), 0,
+        (uint32_t)(p.Cin2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0), 0x00020000);
+    uint32_t xoff[XP], xoff2[XP];
     int hi0[XP], wi0[XP];
 #pragma unroll
     for (int q = 0; q < XP; ++q) {
         const int m = m0 + (wave + NW * q) * 8 + lr;
+        xoff2[q] = kOob;
         if (m < M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hi0[q] = ho * p.stride - p.pad;
             wi0[q] = wo * p.stride - p.pad;
-            xoff[q] = (((long long)b * p.H + hi0[q]) * p.W + wi0[q]) * p.Cin + chunk * 8;
+            // may be "negative" (wraps) for padded rows/cols; adding a valid tap brings it back in range
+            xoff[q] = (uint32_t)(((((long long)b * p.H + hi0[q]) * p.W + wi0[q]) * p.Cin + chunk * 8) * 2);
+            if (p.Cin2)
+                xoff2[q] = (uint32_t)(((((long long)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + chunk * 8) * 2);
         } else {
             hi0[q] = -(1 << 28); // fails every bounds check -> zero rows
             wi0[q] = 0;
             xoff[q] = 0;
         }
     }
-    const bf16_t *wsrc[WP];
+    uint32_t woff[WP];
 #pragma unroll
     for (int q = 0; q < WP; ++q) {
         const int piece = wave + NW * q;
         // LDS row rho = i*16 + fq*4 + r (the MFMA A-operand row) holds output channel
         // (i>>1)*32 + fq*8 + (i&1)*4 + r of the wave's WN-wide slice
         const int rho = (piece < BN / 8 ? piece * 8 + lr : 0);
-        const int rw = rho % WN, i_ = rw >> 4, fq_ = (rw >> 2) & 3, r_ = rw & 3;
-        const int chn = (rho - rw) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
-        wsrc[q] = p.w + (size_t)(n0 + chn) * K + chunk * 8;
+        const int rw_ = rho % WN, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        woff[q] = (uint32_t)(((size_t)(n0 + chn) * K + chunk * 8) * 2);
     }
 
     int ky = 0, kx = 0, kc = 0, kt_load = 0; // position of the NEXT tile to stage
     const int kc_n = p.Cin >> 6;
     auto stage = [&](int buf) {
-        const long long tap = ((long long)ky * p.W + kx) * p.Cin + (kc << 6);
+        if (kt_load < nk1) {
+            const uint32_t tap = (uint32_t)((ky * p.W + kx) * p.Cin * 2); // scalar
 #pragma unroll
-        for (int q = 0; q < XP; ++q) {
-            const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
-            const bf16_t *src = ok ? p.x + xoff[q] + tap : p.zero;
-            glds16(src, Xs + buf * BM * 64 + (wave + NW * q) * 512);
+            for (int q = 0; q < XP; ++q) {
+                const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
+                blds16(rx, ok ? xoff[q] + tap : kOob, (uint32_t)(kc << 7), Xs + buf * BM * 64 + (wave + NW * q) * 512);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < XP; ++q)
+                blds16(rx2, xoff2[q], (uint32_t)((kt_load - nk1) << 7), Xs + buf * BM * 64 + (wave + NW * q) * 512);
         }
 #pragma unroll
         for (int q = 0; q < WP; ++q) {
             const int piece = wave + NW * q;
-            if (piece < BN / 8) glds16(wsrc[q] + (kt_load << 6), Ws + buf * BN * 64 + piece * 512);
+            if (piece < BN / 8) blds16(rw, woff[q], (uint32_t)(kt_load << 7), Ws + buf * BN * 64 + piece * 512);
         }
         ++kt_load;
         if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
@@ -151,15 +180,34 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         }
     }
 
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // optional input affine (+ReLU): per-channel scale/shift staged once in LDS behind the operand slots
+    float *Sc = reinterpret_cast<float *>(Ws + (nk > 1 ? NS : 1) * BN * 64);
+    if (p.in_scale) {
+        for (int c = tid; c < K1; c += NT) {
+            Sc[c] = p.in_scale[c];
+            Sc[K1 + c] = p.in_shift[c];
+        }
+        __syncthreads();
+    }
+    constexpr int PIECES = XP + WP; // LDS-DMA instructions per wave and K-tile
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) stage(t);
 
+    int slot = 0, slot_stage = (NS - 1) % NS;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1); // DMA of the next tile runs under the MFMAs below
-        const bf16_t *xs = Xs + buf * BM * 64 + (wm * WM) * 64;
-        const bf16_t *ws = Ws + buf * BN * 64 + (wn * WN) * 64;
+        // tile kt has landed once all but the (NS-2) younger tiles' DMAs of this wave have retired ...
+        if (NS > 2 && kt + NS - 2 < nk) wait_vmcnt<PIECES *(NS - 2)>();
+        else wait_vmcnt<0>();
+        // ... in every wave; the same barrier frees the slot consumed in step kt-1 for restaging
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) {
+            stage(slot_stage);
+            slot_stage = slot_stage + 1 == NS ? 0 : slot_stage + 1;
+        }
+        const bf16_t *xs = Xs + slot * BM * 64 + (wm * WM) * 64;
+        const bf16_t *ws = Ws + slot * BN * 64 + (wn * WN) * 64;
+        slot = slot + 1 == NS ? 0 : slot + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[TN], bfr[TM];
@@ -174,15 +222,26 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                 const int r = j * 16 + frow;
                 bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3));
             }
+            if (p.in_scale) {
+                // this lane's 8 operand elements are input channels kt*64 + kk*32 + fq*8 .. +7 of one pixel
+                const float *sc = Sc + kt * 64 + kk * 32 + fq * 8;
+                const float4 s0 = *reinterpret_cast<const float4 *>(sc), s1 = *reinterpret_cast<const float4 *>(sc + 4);
+                const float4 t0 = *reinterpret_cast<const float4 *>(sc + K1), t1 = *reinterpret_cast<const float4 *>(sc + K1 + 4);
+                const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    bf16x8 v = bfr[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
+                    bfr[j] = v;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged tile has landed
-            __syncthreads();                                   // ... for every wave; and `buf` is free again
         }
     }
 
@@ -195,6 +254,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
             const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
             bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
             bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+            if (p.bias2) {
+                const float4 d0 = *reinterpret_cast<const float4 *>(p.bias2 + n), d1 = *reinterpret_cast<const float4 *>(p.bias2 + n + 4);
+                bias[0] += d0.x; bias[1] += d0.y; bias[2] += d0.z; bias[3] += d0.w;
+                bias[4] += d1.x; bias[5] += d1.y; bias[6] += d1.z; bias[7] += d1.w;
+            }
         }
         if (p.y2) {
             const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
@@ -258,18 +322,20 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
 static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int grid = ceil_div(M, BM) * (p.Cout / BN);
-    const int nk = p.KH * p.KW * p.Cin / 64;
-    const size_t lds = (size_t)(nk > 1 ? 2 : 1) * (BM + BN) * 64 * sizeof(bf16_t); // single K step: one buffer, more blocks per CU
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
+    const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
+    const size_t slot_bytes = (size_t)(BM + BN) * 64 * sizeof(bf16_t);
+    const size_t aff_bytes = p.in_scale ? (size_t)2 * p.Cin * sizeof(float) : 0;
+    const size_t lds = (nk > 1 ? NS : 1) * slot_bytes + aff_bytes; // single K step: one slot, more blocks per CU
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * 64 * sizeof(bf16_t))));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NS * slot_bytes + 16384)));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
@@ -279,13 +345,30 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 
 int launch_conv(const ConvParams &p, hipStream_t s)
 {
-    if (p.Cin % 64 != 0 || p.Cout % 32 != 0 || !p.zero) {
-        set_error("conv: Cin=%d must be a multiple of 64, Cout=%d of 32, and a zero page is required", p.Cin, p.Cout);
+    if (p.Cin % 64 != 0 || p.Cin2 % 64 != 0 || p.Cout % 32 != 0) {
+        set_error("conv: Cin=%d must be a multiple of 64 and Cout=%d of 32", p.Cin, p.Cout);
         return RFD_ERR_INVALID_ARG;
     }
-    if (p.Cout % 128 == 0) return launch_conv_cfg<128, 128, 2, 2>(p, s);
-    if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1>(p, s);
-    return launch_conv_cfg<128, 32, 4, 1>(p, s);
+    if (p.in_scale && (p.KH != 1 || p.KW != 1 || p.pad != 0 || p.Cin > 2048)) {
+        set_error("conv: the input affine is only defined for un-padded 1x1 convs with Cin <= 2048");
+        return RFD_ERR_INVALID_ARG;
+    }
+    if ((size_t)p.B * p.H * p.W * p.Cin * 2 >= 0xfffffff0ull || (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 >= 0xfffffff0ull) {
+        set_error("conv: an input tensor of %zu bytes exceeds the 4 GiB buffer-addressing limit; lower max_batch_size",
+                  (size_t)p.B * p.H * p.W * p.Cin * 2);
+        return RFD_ERR_CAPACITY;
+    }
+    const int M = p.B * p.Ho * p.Wo;
+    const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
+    if (p.Cout % 128 == 0) {
+        // The 8-wave 256x128 tile with a 3-slot ring (1 workgroup per CU) measured 5-13 % SLOWER than two
+        // co-resident 128x128 workgroups on every layer of this network (profiles/): opt-in only.
+        (void)M; (void)nk;
+        if (p.force_tile == 2) return launch_conv_cfg<256, 128, 4, 2, 3>(p, s);
+        return launch_conv_cfg<128, 128, 2, 2, 2>(p, s);
+    }
+    if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1, 2>(p, s);
+    return launch_conv_cfg<128, 32, 4, 1, 2>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@ struct Layer {
     int cin, cout, kh, kw, stride, pad;
     int has_affine; // per-channel scale2/shift2 (the BN+ReLU that follows a residual add / the pool)
     float gain;     // synthetic-init gain on the He std
-    size_t w_off;   // element offset into the bf16 weight buffer
+    size_t w_off;   // element offset into the bf16 weight buffer (first column of this layer's block)
+    size_t ldw;     // device row pitch in elements (> kh*kw*cin when a shortcut conv shares the rows)
     size_t w_elems; // device elements (conv0 is stored K-padded: 64*7*32)
     size_t b_off;   // float offset of bias; scale2 at b_off+cout, shift2 at b_off+2*cout
 };
@@ -25,6 +26,8 @@ struct Op {
     int kind;
     int layer;
     int in, out, out2, outf, res; // tensor ids, -1 = none
+    int in2, layer2;              // fused second K segment (1x1 shortcut conv on tensor in2), -1 = none
+    int in_affine;                // layer whose post-add affine (+ReLU) is applied to this op's INPUT, -1 = none
     int relu, res_up2, res_post, head_softmax, y_coff;
 };
 
@@ -53,7 +56,7 @@ struct Graph {
   private:
     int add_tensor(int C, int H, int W, int f32 = 0);
     int add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
-                  int has_affine);
+                  int has_affine, int extra_k = 0, int parent = -1, int col_off = 0);
     int add_conv(int layer, int in, int out, int relu, int res = -1, int out2 = -1, int outf = -1);
     void build_r50();
     void plan();
@@ -68,6 +71,7 @@ struct Network {
     bf16_t *d_zero = nullptr;
     std::vector<void *> d_buffers;
     bool profiling = false;
+    int force_tile = 0; // test hook: 0 heuristic, 1 = 128-row tiles only, 2 = 256x128 wherever Cout % 128 == 0
     std::vector<hipEvent_t> ev; // 2 per op when profiling
     std::vector<float> op_ms;   // last profiled run
 

@@ -18,14 +18,23 @@ int Graph::add_tensor(int C, int H, int W, int f32)
     return (int)tensors.size() - 1;
 }
 
+// extra_k > 0: reserve extra_k more columns per row for a fused shortcut conv; parent >= 0: this layer
+// lives in those columns (at col_off) of layer `parent` and allocates nothing.
 int Graph::add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
-                     int has_affine)
+                     int has_affine, int extra_k, int parent, int col_off)
 {
     Layer L;
     L.name = name; L.cin = cin; L.cout = cout; L.kh = k; L.kw = k; L.stride = stride; L.pad = pad;
     L.gain = gain; L.has_affine = has_affine;
-    L.w_off = w_total;
-    L.w_elems = (k == 7 && cin == 3) ? (size_t)cout * 7 * 32 : (size_t)cout * k * k * cin;
+    if (parent >= 0) {
+        L.w_off = layers[parent].w_off + col_off;
+        L.ldw = layers[parent].ldw;
+        L.w_elems = 0;
+    } else {
+        L.w_off = w_total;
+        L.ldw = (k == 7 && cin == 3) ? 7 * 32 : (size_t)k * k * cin + extra_k;
+        L.w_elems = (size_t)cout * L.ldw;
+    }
     w_total += (L.w_elems + 63) & ~(size_t)63; // keep every layer 128-byte aligned
     L.b_off = b_total;
     b_total += (size_t)3 * cout;
@@ -37,6 +46,7 @@ int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int
 {
     Op o;
     o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
+    o.in2 = -1; o.layer2 = -1; o.in_affine = -1;
     o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
     ops.push_back(o);
     return (int)ops.size() - 1;
@@ -53,17 +63,18 @@ void Graph::build_r50()
     const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1);
     const int t_c0 = add_tensor(64, H / 2, W / 2);
     {
-        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, 1, 0, 0, 0, 0};
+        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, -1, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, 1, 0, 0, 0, 0};
+        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, -1, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
     static const int mids[4] = {64, 128, 256, 512};
     int x_act = t_p, x_raw = -1, cin = 64, h = H / 4, w = W / 4;
+    int prev_l3 = -1; // conv3 layer of the previous unit when its BN+ReLU output was NOT materialised
     int c_out[4] = {-1, -1, -1, -1};
     for (int s = 0; s < 4; ++s) {
         const int mid = mids[s], cout = mid * 4;
@@ -75,25 +86,35 @@ void Graph::build_r50()
             snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 1);
             const int l1 = add_layer(nm, cin, mid, 1, 1, 0, 1.0f, 0);
             const int t1 = add_tensor(mid, h, w);
-            add_conv(l1, x_act, t1, 1);
+            {
+                // inside a stage the previous unit stores only its raw sum; its BN+ReLU ("act") is applied
+                // to this conv's input fragments on the fly instead of round-tripping a second tensor
+                const int o1 = add_conv(l1, x_act >= 0 ? x_act : x_raw, t1, 1);
+                if (x_act < 0) ops[o1].in_affine = prev_l3;
+            }
             snprintf(nm, sizeof nm, "stage%d_unit%d_conv2", s + 1, u + 1);
             const int l2 = add_layer(nm, mid, mid, 3, stride, 1, 1.0f, 0);
             const int t2 = add_tensor(mid, ho, wo);
             add_conv(l2, t1, t2, 1);
-            int res = x_raw;
+            // conv3 (+ identity residual) -- or, in the first unit of a stage, conv3 and the 1x1 shortcut
+            // conv fused as ONE GEMM over the concatenated K = [mid | cin]: the shortcut tensor never exists
+            snprintf(nm, sizeof nm, "stage%d_unit%d_conv3", s + 1, u + 1);
+            const int l3 = add_layer(nm, mid, cout, 1, 1, 0, 1.0f, 1, dim_match ? 0 : cin);
+            int ls = -1;
             if (!dim_match) {
                 snprintf(nm, sizeof nm, "stage%d_unit%d_sc", s + 1, u + 1);
-                const int ls = add_layer(nm, cin, cout, 1, stride, 0, 1.0f, 0);
-                res = add_tensor(cout, ho, wo);
-                add_conv(ls, x_act, res, 0);
+                ls = add_layer(nm, cin, cout, 1, stride, 0, 1.0f, 0, 0, l3, mid);
             }
-            snprintf(nm, sizeof nm, "stage%d_unit%d_conv3", s + 1, u + 1);
-            const int l3 = add_layer(nm, mid, cout, 1, 1, 0, 1.0f, 1);
-            const bool need_raw = u + 1 < units[s];
-            const int t_raw = need_raw ? add_tensor(cout, ho, wo) : -1;
-            const int t_act = add_tensor(cout, ho, wo);
-            add_conv(l3, t2, t_raw, 0, res, t_act);
-            x_raw = t_raw; x_act = t_act; cin = cout; h = ho; w = wo;
+            const bool last = u + 1 == units[s];
+            // Stages 1-2 (huge, memory-bound tensors): only stage outputs materialise BN+ReLU, the units in
+            // between hand over the raw sum alone.  Stages 3-4 (K >= 1024 conv1s, compute-bound): applying the
+            // affine in the consumer costs more VALU than the store it saves (measured), so both are written.
+            const bool fuse_act = s < 2;
+            const int t_raw = last ? -1 : add_tensor(cout, ho, wo);
+            const int t_act = (last || !fuse_act) ? add_tensor(cout, ho, wo) : -1;
+            const int o3 = add_conv(l3, t2, t_raw, 0, dim_match ? x_raw : -1, t_act);
+            if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
+            x_raw = t_raw; x_act = t_act; prev_l3 = l3; cin = cout; h = ho; w = wo;
         }
         c_out[s] = x_act;
     }
@@ -159,6 +180,7 @@ void Graph::plan()
     for (int i = 0; i < nops; ++i) {
         const Op &o = ops[i];
         touch(o.in, i, false);
+        touch(o.in2, i, false);
         touch(o.res, i, false);
         touch(o.out, i, true);
         touch(o.out2, i, true);
@@ -221,7 +243,9 @@ double Graph::layer_macs(int i) const
     if (o.kind == OP_POOL) return 0.0;
     const Layer &L = layers[o.layer];
     const int t = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
-    return (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
+    double m = (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
+    if (o.layer2 >= 0) m += (double)tensors[t].H * tensors[t].W * L.cout * layers[o.layer2].cin;
+    return m;
 }
 
 double Graph::macs_per_image() const
@@ -335,7 +359,8 @@ int Network::set_layer(int idx, const float *w, const float *bias, hipStream_t s
 {
     if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
-    std::vector<bf16_t> hw(L.w_elems, 0);
+    const size_t K = (L.kh == 7 && L.cin == 3) ? 7 * 32 : (size_t)L.kh * L.kw * L.cin;
+    std::vector<bf16_t> hw((size_t)L.cout * K, 0);
     if (L.kh == 7 && L.cin == 3) { // [64][7][7][3] -> [64][7][8 kx][4 c], zero padded
         for (int n = 0; n < L.cout; ++n)
             for (int ky = 0; ky < 7; ++ky)
@@ -343,9 +368,10 @@ int Network::set_layer(int idx, const float *w, const float *bias, hipStream_t s
                     for (int c = 0; c < 3; ++c)
                         hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c] = f32_to_bf16_host(w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c]);
     } else {
-        for (size_t i = 0; i < L.w_elems; ++i) hw[i] = f32_to_bf16_host(w[i]);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = f32_to_bf16_host(w[i]);
     }
-    RFD_HIP(hipMemcpyAsync(d_w + L.w_off, hw.data(), L.w_elems * sizeof(bf16_t), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipMemcpy2DAsync(d_w + L.w_off, L.ldw * sizeof(bf16_t), hw.data(), K * sizeof(bf16_t), K * sizeof(bf16_t),
+                             L.cout, hipMemcpyHostToDevice, s));
     if (bias) RFD_HIP(hipMemcpyAsync(d_b + L.b_off, bias, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
     RFD_HIP(hipStreamSynchronize(s)); // hw goes out of scope
     return RFD_OK;
@@ -356,8 +382,10 @@ int Network::get_layer(int idx, float *w, float *bias, hipStream_t s)
     if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
     if (w) {
-        std::vector<bf16_t> hw(L.w_elems);
-        RFD_HIP(hipMemcpyAsync(hw.data(), d_w + L.w_off, L.w_elems * sizeof(bf16_t), hipMemcpyDeviceToHost, s));
+        const size_t K = (L.kh == 7 && L.cin == 3) ? 7 * 32 : (size_t)L.kh * L.kw * L.cin;
+        std::vector<bf16_t> hw((size_t)L.cout * K);
+        RFD_HIP(hipMemcpy2DAsync(hw.data(), K * sizeof(bf16_t), d_w + L.w_off, L.ldw * sizeof(bf16_t), K * sizeof(bf16_t),
+                                 L.cout, hipMemcpyDeviceToHost, s));
         RFD_HIP(hipStreamSynchronize(s));
         if (L.kh == 7 && L.cin == 3) {
             for (int n = 0; n < L.cout; ++n)
@@ -366,7 +394,7 @@ int Network::get_layer(int idx, float *w, float *bias, hipStream_t s)
                         for (int c = 0; c < 3; ++c)
                             w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c] = bf16_to_f32_host(hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c]);
         } else {
-            for (size_t i = 0; i < L.w_elems; ++i) w[i] = bf16_to_f32_host(hw[i]);
+            for (size_t i = 0; i < hw.size(); ++i) w[i] = bf16_to_f32_host(hw[i]);
         }
     }
     if (bias) {
@@ -427,7 +455,20 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
             p.w = d_w + L.w_off;
             p.bias = d_b + L.b_off;
             p.zero = d_zero;
+            p.force_tile = force_tile;
             p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
+            if (o.layer2 >= 0) {
+                const Layer &L2 = g.layers[o.layer2];
+                const TensorDesc &t2 = g.tensors[o.in2];
+                p.x2 = (const bf16_t *)tensor_ptr(o.in2);
+                p.bias2 = d_b + L2.b_off;
+                p.H2 = t2.H; p.W2 = t2.W; p.Cin2 = L2.cin; p.stride2 = L2.stride;
+            }
+            if (o.in_affine >= 0) {
+                const Layer &La = g.layers[o.in_affine];
+                p.in_scale = d_b + La.b_off + La.cout;
+                p.in_shift = d_b + La.b_off + 2 * La.cout;
+            }
             p.scale2 = d_b + L.b_off + L.cout;
             p.shift2 = d_b + L.b_off + 2 * L.cout;
             p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out) : nullptr;

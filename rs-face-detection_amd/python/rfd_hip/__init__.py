@@ -70,7 +70,8 @@ class rfd_op_desc(C.Structure):
     _fields_ = [("kind", C.c_int), ("layer", C.c_int), ("in_", C.c_int), ("out", C.c_int),
                 ("out2", C.c_int), ("outf", C.c_int), ("res", C.c_int), ("relu", C.c_int),
                 ("res_up2", C.c_int), ("res_post", C.c_int), ("head_softmax", C.c_int),
-                ("y_coff", C.c_int), ("macs", C.c_double), ("reserved", C.c_int * 4)]
+                ("y_coff", C.c_int), ("macs", C.c_double), ("in2", C.c_int), ("layer2", C.c_int),
+                ("in_affine", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class rfd_tensor_desc(C.Structure):
@@ -88,7 +89,7 @@ API_SYMBOLS = [
     "rfd_set_layer_weights", "rfd_get_layer_affine", "rfd_set_layer_affine", "rfd_detect_batch",
     "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
-    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops",
+    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile",
 ]
 
 _lib = None
@@ -146,6 +147,7 @@ def load_library(path=None):
     L.rfd_get_op_profile.argtypes = [vp, vp, ci]
     L.rfd_debug_tensor_io.argtypes = [vp, ci, ci, vp, ci]
     L.rfd_debug_run_ops.argtypes = [vp, ci, ci, ci]
+    L.rfd_debug_set_conv_tile.argtypes = [vp, ci]
     if path is None:
         _lib = L
     return L
@@ -393,6 +395,9 @@ class RetinaFaceDetection:
         a = np.zeros((n, desc.height, desc.width, desc.channels), dt)
         _check(self._L.rfd_debug_tensor_io(self._ctx, tensor_id, n, a.ctypes.data, 0))
         return a
+
+    def debug_set_conv_tile(self, tile):
+        _check(self._L.rfd_debug_set_conv_tile(self._ctx, tile))
 
     def debug_run(self, n, first_op, last_op):
         _check(self._L.rfd_debug_run_ops(self._ctx, n, first_op, last_op))

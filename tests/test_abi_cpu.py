@@ -35,7 +35,9 @@ def test_graph_matches_survey_appendix_b(rfd):
     assert abs(g.macs - 44.2646528e9) < 1e3          # 44.265 GMAC / image
     convs = [o for o in g.ops if o.kind in (0, 2)]
     heads = [o for o in g.ops if o.head_softmax]
-    assert len(convs) + 2 * len(heads) == 82           # 9 head convs run as 3 fused N=32 GEMMs
+    fused_sc = [o for o in g.ops if o.layer2 >= 0]     # 4 shortcut convs ride in their conv3's GEMM
+    assert len(convs) + 2 * len(heads) + len(fused_sc) == 82  # 9 head convs run as 3 fused N=32 GEMMs
+    assert len(fused_sc) == 4 and g.num_layers == 76
     assert sorted(t.head_level for t in g.tensors if t.head_level) == [1, 2, 3]
     hl = {t.head_level: (t.height, t.width, t.channels) for t in g.tensors if t.head_level}
     assert hl == {1: (20, 20, 32), 2: (40, 40, 32), 3: (80, 80, 32)}

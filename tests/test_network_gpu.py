@@ -45,12 +45,18 @@ def _check_close(got, want, what):
     return float(np.mean(got == want))
 
 
-def test_every_op_in_isolation(rfd, net):
+@pytest.mark.parametrize("tile", [1, 2])
+def test_every_op_in_isolation(rfd, net, tile):
+    """tile 1: every conv on the 128-row, 2-slot tiles; tile 2: the 256x128, 3-slot-ring tile wherever
+    Cout % 128 == 0 (the heuristic picks between them by grid size at run time)."""
     det, g, ref = net
+    det.debug_set_conv_tile(tile)
     rng = np.random.default_rng(99)
     n = 2
     exact = []
     for i, o in enumerate(g.ops):
+        if tile == 2 and (o.kind != 2 or g.layers[o.layer].cout % 128):
+            continue
         tens = {}
         tin = g.tensors[o.in_]
         if o.kind == 0:
@@ -58,8 +64,11 @@ def test_every_op_in_isolation(rfd, net):
             x[:, 3] = 0
             tens[o.in_] = torch.from_numpy(x)
         else:
-            tens[o.in_] = _rand_act(rng, n, tin)
+            tens[o.in_] = _rand_act(rng, n, tin, relu_like=o.in_affine < 0)
         det.debug_write(o.in_, torch_ref.nchw_to_dev(tens[o.in_]))
+        if o.in2 >= 0:
+            tens[o.in2] = _rand_act(rng, n, g.tensors[o.in2])
+            det.debug_write(o.in2, torch_ref.nchw_to_dev(tens[o.in2]))
         if o.res >= 0:
             tens[o.res] = _rand_act(rng, n, g.tensors[o.res], relu_like=False)
             det.debug_write(o.res, torch_ref.nchw_to_dev(tens[o.res]))
@@ -76,6 +85,7 @@ def test_every_op_in_isolation(rfd, net):
             td = g.tensors[t]
             got = torch_ref.dev_to_nchw(det.debug_read(t, n, td), bool(td.is_f32))
             exact.append(_check_close(got, tens[t], "op %d (%s) tensor %d" % (i, g.layers[o.layer].name.decode(), t)))
+    det.debug_set_conv_tile(0)
     assert np.mean(exact) > 0.97  # nearly every bf16 output is bit-identical to the torch result
 
 
@@ -89,6 +99,9 @@ def test_batch_tail_rows(rfd, net):
             continue
         tens = {o.in_: _rand_act(rng, 1, g.tensors[o.in_])}
         det.debug_write(o.in_, torch_ref.nchw_to_dev(tens[o.in_]))
+        if o.in2 >= 0:
+            tens[o.in2] = _rand_act(rng, 1, g.tensors[o.in2])
+            det.debug_write(o.in2, torch_ref.nchw_to_dev(tens[o.in2]))
         if o.res >= 0:
             tens[o.res] = _rand_act(rng, 1, g.tensors[o.res], relu_like=False)
             det.debug_write(o.res, torch_ref.nchw_to_dev(tens[o.res]))

@@ -44,7 +44,13 @@ class TorchRef:
             s, t = self.aff[o.layer]
             tensors[o.out] = bf16r(F.relu(v * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
             return
+        if o.in_affine >= 0:  # BN+ReLU of the producer unit, applied to this conv's input (rounded to bf16)
+            s, t = self.aff[o.in_affine]
+            x = bf16r(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
         v = F.conv2d(x, self.w[o.layer], self.b[o.layer], stride=L.stride, padding=L.pad)
+        if o.layer2 >= 0:  # the 1x1 shortcut conv fused as a second K segment of the same GEMM
+            L2 = g.layers[o.layer2]
+            v = v + F.conv2d(tensors[o.in2], self.w[o.layer2], self.b[o.layer2], stride=L2.stride)
         r = None
         if o.res >= 0:
             r = tensors[o.res]
