@@ -58,9 +58,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// NS = slots of the LDS operand ring: NS - 1 K-tiles are in flight (LDS-DMA) or being consumed while
-// one is free; a counted s_waitcnt vmcnt leaves the younger tiles in flight across the barrier.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+// LDS operand rings: NSX slots for the activation (im2col) tile, 2 for the weight tile.  With NSX = 3 the
+// activation tile of step kt+2 is requested while step kt computes (HBM/L2 latency gets two steps of
+// cover), the L2-hot weight tile one step ahead; per step the weight DMAs are issued BEFORE the younger
+// activation DMAs, so a counted `s_waitcnt vmcnt(XP)` retires everything step kt needs and leaves the
+// activation tile kt+1 in flight across the barrier.  128x128: 3*16 + 2*16 = 80 KiB -> two workgroups
+// fill the CU's 160 KiB exactly.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = WAVES_M * WAVES_N;
@@ -81,7 +85,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     const int K1 = p.KH * p.KW * p.Cin;
     const int K = K1 + p.Cin2; // second K segment: the fused 1x1 shortcut conv
     const int nk1 = K1 >> 6, nk = K >> 6;
-    bf16_t *Ws = Xs + (nk > 1 ? NS : 1) * BM * 64;             // [slots][BN*64]; one slot for a single K step
+    bf16_t *Ws = Xs + (nk > 1 ? NSX : 1) * BM * 64;            // [2][BN*64]; one slot each for a single K step
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
@@ -130,28 +134,31 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         woff[q] = (uint32_t)(((size_t)(n0 + chn) * K + chunk * 8) * 2);
     }
 
-    int ky = 0, kx = 0, kc = 0, kt_load = 0; // position of the NEXT tile to stage
+    int ky = 0, kx = 0, kc = 0, kt_x = 0, kt_w = 0; // positions of the NEXT tiles to stage
     const int kc_n = p.Cin >> 6;
-    auto stage = [&](int buf) {
-        if (kt_load < nk1) {
+    auto stage_x = [&](int slot) {
+        if (kt_x < nk1) {
             const uint32_t tap = (uint32_t)((ky * p.W + kx) * p.Cin * 2); // scalar
 #pragma unroll
             for (int q = 0; q < XP; ++q) {
                 const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
-                blds16(rx, ok ? xoff[q] + tap : kOob, (uint32_t)(kc << 7), Xs + buf * BM * 64 + (wave + NW * q) * 512);
+                blds16(rx, ok ? xoff[q] + tap : kOob, (uint32_t)(kc << 7), Xs + slot * BM * 64 + (wave + NW * q) * 512);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < XP; ++q)
-                blds16(rx2, xoff2[q], (uint32_t)((kt_load - nk1) << 7), Xs + buf * BM * 64 + (wave + NW * q) * 512);
+                blds16(rx2, xoff2[q], (uint32_t)((kt_x - nk1) << 7), Xs + slot * BM * 64 + (wave + NW * q) * 512);
         }
+        ++kt_x;
+        if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+    };
+    auto stage_w = [&](int slot) {
 #pragma unroll
         for (int q = 0; q < WP; ++q) {
             const int piece = wave + NW * q;
-            if (piece < BN / 8) blds16(rw, woff[q], (uint32_t)(kt_load << 7), Ws + buf * BN * 64 + piece * 512);
+            if (piece < BN / 8) blds16(rw, woff[q], (uint32_t)(kt_w << 7), Ws + slot * BN * 64 + piece * 512);
         }
-        ++kt_load;
-        if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+        ++kt_w;
     };
 
     f32x4 acc[TN][TM];
@@ -181,7 +188,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     }
 
     // optional input affine (+ReLU): per-channel scale/shift staged once in LDS behind the operand slots
-    float *Sc = reinterpret_cast<float *>(Ws + (nk > 1 ? NS : 1) * BN * 64);
+    float *Sc = reinterpret_cast<float *>(Ws + (nk > 1 ? 2 : 1) * BN * 64);
     if (p.in_scale) {
         for (int c = tid; c < K1; c += NT) {
             Sc[c] = p.in_scale[c];
@@ -189,25 +196,32 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         }
         __syncthreads();
     }
-    constexpr int PIECES = XP + WP; // LDS-DMA instructions per wave and K-tile
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) stage(t);
+    // prologue, in queue order: X0, W0, (X1)
+    stage_x(0);
+    stage_w(0);
+    if (NSX > 2 && nk > 1) stage_x(1);
 
-    int slot = 0, slot_stage = (NS - 1) % NS;
+    int xslot = 0, wslot = 0, xstage = NSX - 1, wstage = 1;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once all but the (NS-2) younger tiles' DMAs of this wave have retired ...
-        if (NS > 2 && kt + NS - 2 < nk) wait_vmcnt<PIECES *(NS - 2)>();
+        // step kt needs X(kt), W(kt): with the 3-slot X ring only X(kt+1) (the youngest XP DMAs of this
+        // wave) may still be in flight
+        if (NSX > 2 && kt + 1 < nk) wait_vmcnt<XP>();
         else wait_vmcnt<0>();
-        // ... in every wave; the same barrier frees the slot consumed in step kt-1 for restaging
+        // ... in every wave; the same barrier frees the slots consumed in step kt-1 for restaging
         asm volatile("s_barrier" ::: "memory");
-        if (kt + NS - 1 < nk) {
-            stage(slot_stage);
-            slot_stage = slot_stage + 1 == NS ? 0 : slot_stage + 1;
+        if (kt + 1 < nk) {
+            stage_w(wstage);
+            wstage ^= 1;
         }
+        if (kt + NSX - 1 < nk) {
+            stage_x(xstage);
+            xstage = xstage + 1 == NSX ? 0 : xstage + 1;
+        }
+        const int slot = xslot;
+        xslot = xslot + 1 == NSX ? 0 : xslot + 1;
         const bf16_t *xs = Xs + slot * BM * 64 + (wm * WM) * 64;
-        const bf16_t *ws = Ws + slot * BN * 64 + (wn * WN) * 64;
-        slot = slot + 1 == NS ? 0 : slot + 1;
+        const bf16_t *ws = Ws + wslot * BN * 64 + (wn * WN) * 64;
+        wslot ^= 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[TN], bfr[TM];
@@ -322,20 +336,21 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
 static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int grid = ceil_div(M, BM) * (p.Cout / BN);
     const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
-    const size_t slot_bytes = (size_t)(BM + BN) * 64 * sizeof(bf16_t);
+    const size_t full = (size_t)(NSX * BM + 2 * BN) * 64 * sizeof(bf16_t);
     const size_t aff_bytes = p.in_scale ? (size_t)2 * p.Cin * sizeof(float) : 0;
-    const size_t lds = (nk > 1 ? NS : 1) * slot_bytes + aff_bytes; // single K step: one slot, more blocks per CU
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NS>;
+    // single K step: one slot each, more workgroups per CU
+    const size_t lds = (nk > 1 ? full : (size_t)(BM + BN) * 64 * sizeof(bf16_t)) + aff_bytes;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NSX>;
     static bool attr_set = false;
     if (!attr_set) {
         RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NS * slot_bytes + 16384)));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(full + 16384)));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
@@ -365,8 +380,11 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         // co-resident 128x128 workgroups on every layer of this network (profiles/): opt-in only.
         (void)M; (void)nk;
         if (p.force_tile == 2) return launch_conv_cfg<256, 128, 4, 2, 3>(p, s);
-        return launch_conv_cfg<128, 128, 2, 2, 2>(p, s);
+        // the 80 KiB ring leaves no room for the input-affine table next to a second workgroup
+        if (p.force_tile == 1 || p.in_scale) return launch_conv_cfg<128, 128, 2, 2, 2>(p, s);
+        return launch_conv_cfg<128, 128, 2, 2, 3>(p, s);
     }
+    // 128x64: the 2-slot ring keeps 3 workgroups per CU, which measured faster than a deeper ring at 2
     if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1, 2>(p, s);
     return launch_conv_cfg<128, 32, 4, 1, 2>(p, s);
 }
