@@ -189,9 +189,11 @@ int launch_sort(const uint64_t *keys, const int *count, const float *rows, uint6
 // Survivor rule: a later box survives iff `ovr <= thresh` (nms.rs:58) -- a NaN overlap suppresses.
 // IoU: +1 pixel convention, inter / (area_i + area_j - inter) in f32 (nms.rs:39-54).
 // ------------------------------------------------------------------------------------------------
-constexpr int kNmsThreads = 512;
+constexpr int kNmsThreads = 1024;
 constexpr int kNmsWaves = kNmsThreads / 64;
-constexpr int kNmsLdsBoxes = 4096; // sorted boxes cached in LDS (64 KiB); the rest stream from L2
+constexpr int kNmsRegWords = 17;    // bitmap words (64 candidates each) a wave can own in registers
+constexpr int kNmsRegCap = kNmsRegWords * kNmsWaves * 64; // 17408 >= the 16800 anchors of a 640x640 input
+constexpr int kNmsLdsBoxes = 4096;  // REG = false only: sorted boxes cached in LDS, the rest stream from L2
 
 __device__ __forceinline__ float box_area(const float4 b)
 {
@@ -199,7 +201,7 @@ __device__ __forceinline__ float box_area(const float4 b)
 }
 
 __device__ __forceinline__ bool suppresses(const float4 bi, const float area_i, const float4 bj,
-                                           const float thresh)
+                                           const float area_j, const float thresh)
 {
     const float xx1 = fmaxf(bi.x, bj.x);
     const float yy1 = fmaxf(bi.y, bj.y);
@@ -210,22 +212,29 @@ __device__ __forceinline__ bool suppresses(const float4 bi, const float area_i, 
     w = fmaxf(0.0f, w);
     h = fmaxf(0.0f, h);
     const float inter = w * h;
-    const float area_j = box_area(bj);
-    const float ovr = inter / (area_i + area_j - inter);
+    const float uni = area_i + area_j - inter;
+    const float ovr = inter / uni;
     return !(ovr <= thresh);
 }
 
+// REG: every wave keeps the boxes of the bitmap words it owns (w = wave, wave+16, ...) in registers, so
+// the suppression scan reads only the 64 kept-candidate boxes of the current tile from LDS.  Used when
+// the candidate capacity fits (<= 17408); otherwise boxes are re-read from an LDS cache / L2.
+template <bool REG>
 __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve (all offsets multiples of 16)
-    float4 *lds_boxes = reinterpret_cast<float4 *>(smem);                                   // [kNmsLdsBoxes]
-    float4 *tile_boxes = lds_boxes + kNmsLdsBoxes;                                           // [64]
+    float4 *tile_boxes = reinterpret_cast<float4 *>(smem);                                   // [64]
     uint64_t *removed = reinterpret_cast<uint64_t *>(tile_boxes + 64);                       // [nwords_cap]
-    uint64_t *kept_word = removed + p.nwords_cap;                                            // [2]
+    uint64_t *keptw = removed + p.nwords_cap;                                                // [nwords_cap]
+    int *obase = reinterpret_cast<int *>(keptw + p.nwords_cap);                              // [nwords_cap]
+    uint64_t *kept_word = reinterpret_cast<uint64_t *>(obase + p.nwords_cap);                // [2]
+    float4 *lds_boxes = reinterpret_cast<float4 *>(kept_word + 2);                           // [kNmsLdsBoxes] (!REG)
 
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = p.presorted_n >= 0 ? p.presorted_n : p.count[b];
     const int ntiles = (n + 63) >> 6;
     const float4 *sb = p.sorted_boxes + (size_t)b * p.total_anchors;
@@ -234,16 +243,35 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
     for (int w = tid; w < ntiles; w += kNmsThreads) {
         const int rem = n - w * 64;
         removed[w] = rem >= 64 ? 0ull : ~((1ull << rem) - 1ull); // slots >= n are dead
+        keptw[w] = 0ull;
     }
-    for (int j = tid; j < min(n, kNmsLdsBoxes); j += kNmsThreads) lds_boxes[j] = sb[j];
+    float4 mybox[REG ? kNmsRegWords : 1];
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < kNmsRegWords; ++k) {
+            const int j = (wave + k * kNmsWaves) * 64 + lane;
+            mybox[k] = j < n ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        for (int j = tid; j < min(n, kNmsLdsBoxes); j += kNmsThreads) lds_boxes[j] = sb[j];
+    }
     __syncthreads();
 
-    int kept_base = 0; // meaningful in wave 0 only
     for (int t = 0; t < ntiles; ++t) {
-        if (wave == 0) {
-            const int j = t * 64 + lane;
+        // ---- resolve tile t: by the wave that holds its boxes in registers (REG) or by wave 0 ----
+        const int owner = REG ? (t & (kNmsWaves - 1)) : 0;
+        if (wave == owner) {
             float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < n) box = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
+            if (REG) {
+                const int kk = t / kNmsWaves; // wave-uniform
+#pragma unroll
+                for (int k = 0; k < kNmsRegWords; ++k)
+                    if (k == kk) box = mybox[k];
+            } else {
+                const int j = t * 64 + lane;
+                if (j < n) box = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
+            }
+            const float area = box_area(box);
             tile_boxes[lane] = box;
             __builtin_amdgcn_wave_barrier();
             const uint64_t rem_t = removed[t];
@@ -252,13 +280,15 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_t));
             uint64_t kept = 0;
             if (alive0 != 0ull) {
-                // intra-tile masks: lane i marks every later lane jj it would suppress
-                const float area = box_area(box);
+                // intra-tile masks: lane i marks every later, still-alive lane jj it would suppress
                 uint64_t mask = 0;
-                for (int jj = 0; jj < 64; ++jj) {
-                    // lanes read the same LDS address: a broadcast
+                uint64_t cand = alive0;
+                while (cand != 0ull) { // wave-uniform walk over the alive candidates only
+                    const int jj = __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    // same address in every lane: a broadcast
                     const float4 other = tile_boxes[jj];
-                    if (jj > lane && suppresses(box, area, other, thresh)) mask |= 1ull << jj;
+                    if (jj > lane && suppresses(box, area, other, box_area(other), thresh)) mask |= 1ull << jj;
                 }
                 // greedy resolve in score order; `alive` is wave-uniform
                 uint64_t alive = alive0;
@@ -270,87 +300,124 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
                     const uint64_t mi = ((uint64_t)mhi << 32) | mlo;
                     alive &= ~(mi | (1ull << i));
                 }
-                // emit kept rows (face_detection.rs:433-464) rescaled by det_scale (:473-493)
-                if ((kept >> lane) & 1ull) {
-                    const int o = kept_base + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
-                    if (o < p.max_det) {
-                        uint32_t g = (uint32_t)j;
-                        if (p.rows) {
-                            g = (uint32_t)p.sorted_keys[(size_t)b * p.total_anchors + j];
-                            float *ob = p.out_boxes + ((size_t)b * p.max_det + o) * 5;
-                            const float4 *row = reinterpret_cast<const float4 *>(
-                                p.rows + ((size_t)b * p.total_anchors + g) * kDetRow);
-                            const float sc = p.det_scale[b];
-                            const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-                            ob[0] = r0.x / sc; ob[1] = r0.y / sc; ob[2] = r0.z / sc; ob[3] = r0.w / sc;
-                            ob[4] = r1.x;
-                            float *ol = p.out_lmk + ((size_t)b * p.max_det + o) * 10;
-                            ol[0] = r1.y / sc; ol[1] = r1.z / sc; ol[2] = r1.w / sc;
-                            ol[3] = r2.x / sc; ol[4] = r2.y / sc; ol[5] = r2.z / sc; ol[6] = r2.w / sc;
-                            ol[7] = r3.x / sc; ol[8] = r3.y / sc; ol[9] = r3.z / sc;
-                        }
-                        if (p.out_gidx) p.out_gidx[(size_t)b * p.max_det + o] = (int)g;
-                    }
-                }
-                kept_base += __builtin_popcountll(kept);
             }
-            if (lane == 0) kept_word[0] = kept;
+            if (lane == 0) { kept_word[0] = kept; keptw[t] = kept; }
         }
         __syncthreads();
+        // ---- all waves: test every still-alive later candidate against the KEPT boxes of tile t ----
         const uint64_t kmask = kept_word[0];
         if (kmask != 0ull) {
             // every wave owns whole bitmap words: one ballot, one plain LDS store, no atomics
-            for (int w = t + 1 + wave; w < ntiles; w += kNmsWaves) {
+            auto scan_word = [&](int w, const float4 bj) {
                 const uint64_t rw = removed[w];
-                if (rw == ~0ull) continue; // wave-uniform
-                const int j = w * 64 + lane;
-                const bool live = !((rw >> lane) & 1ull);
+                if (rw == ~0ull) return; // wave-uniform
+                const float area_j = box_area(bj);
                 bool sup = false;
-                if (live) {
-                    const float4 bj = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
-                    uint64_t km = kmask;
-                    while (km != 0ull && !sup) {
-                        const int i = __builtin_ctzll(km);
-                        km &= km - 1ull;
-                        const float4 bi = tile_boxes[i];
-                        sup = suppresses(bi, box_area(bi), bj, thresh);
-                    }
+                uint64_t km = kmask;
+                while (km != 0ull) { // wave-uniform trip count; ONE LDS broadcast per step (area recomputed:
+                    const int i = __builtin_ctzll(km); // a second LDS read per step measured 45 % slower)
+                    km &= km - 1ull;
+                    const float4 bi = tile_boxes[i];
+                    sup |= suppresses(bi, box_area(bi), bj, area_j, thresh);
                 }
                 const uint64_t bal = __ballot(sup);
-                if (lane == 0 && bal != 0ull) removed[w] = rw | bal;
+                if (lane == 0 && (bal & ~rw) != 0ull) removed[w] = rw | bal;
+            };
+            if (REG) {
+#pragma unroll
+                for (int k = 0; k < kNmsRegWords; ++k) {
+                    const int w = wave + k * kNmsWaves;
+                    if (w > t && w < ntiles) scan_word(w, mybox[k]);
+                }
+            } else {
+                for (int w = t + 1 + wave; w < ntiles; w += kNmsWaves) {
+                    const int j = w * 64 + lane;
+                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < n) bj = j < kNmsLdsBoxes ? lds_boxes[j] : sb[j];
+                    scan_word(w, bj);
+                }
             }
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        if (p.out_total) p.out_total[b] = kept_base;
-        if (p.out_count) p.out_count[b] = min(kept_base, p.max_det);
+
+    // ---- emit the kept rows in score order (face_detection.rs:433-464), rescaled (:473-493): exclusive
+    //      prefix of the per-word kept counts (wave 0), then every thread gathers its own candidates ----
+    if (wave == 0) {
+        const int per = (ntiles + 63) >> 6;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) {
+            const int w = lane * per + k;
+            if (w < ntiles) sum += __builtin_popcountll(keptw[w]);
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        int run = incl - sum;
+        for (int k = 0; k < per; ++k) {
+            const int w = lane * per + k;
+            if (w < ntiles) { obase[w] = run; run += __builtin_popcountll(keptw[w]); }
+        }
+        if (lane == 63) {
+            if (p.out_total) p.out_total[b] = incl;
+            if (p.out_count) p.out_count[b] = min(incl, p.max_det);
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += kNmsThreads) {
+        const uint64_t kw = keptw[j >> 6];
+        if (!((kw >> (j & 63)) & 1ull)) continue;
+        const int o = obase[j >> 6] + __builtin_popcountll(kw & ((1ull << (j & 63)) - 1ull));
+        if (o >= p.max_det) continue;
+        uint32_t g = (uint32_t)j;
+        if (p.rows) {
+            g = (uint32_t)p.sorted_keys[(size_t)b * p.total_anchors + j];
+            float *ob = p.out_boxes + ((size_t)b * p.max_det + o) * 5;
+            const float4 *row = reinterpret_cast<const float4 *>(p.rows + ((size_t)b * p.total_anchors + g) * kDetRow);
+            const float sc = p.det_scale[b];
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            ob[0] = r0.x / sc; ob[1] = r0.y / sc; ob[2] = r0.z / sc; ob[3] = r0.w / sc;
+            ob[4] = r1.x;
+            float *ol = p.out_lmk + ((size_t)b * p.max_det + o) * 10;
+            ol[0] = r1.y / sc; ol[1] = r1.z / sc; ol[2] = r1.w / sc;
+            ol[3] = r2.x / sc; ol[4] = r2.y / sc; ol[5] = r2.z / sc; ol[6] = r2.w / sc;
+            ol[7] = r3.x / sc; ol[8] = r3.y / sc; ol[9] = r3.z / sc;
+        }
+        if (p.out_gidx) p.out_gidx[(size_t)b * p.max_det + o] = (int)g;
     }
 }
 
-size_t nms_lds_bytes(int total_anchors)
+size_t nms_lds_bytes(int total_anchors, bool reg)
 {
     const int nwords = ceil_div(total_anchors, 64);
-    const int nwords_cap = (nwords + 1) & ~1;
-    return (size_t)(kNmsLdsBoxes + 64) * sizeof(float4) + (size_t)(nwords_cap + 2) * sizeof(uint64_t);
+    const int nwords_cap = (nwords + 3) & ~3;
+    return (size_t)64 * sizeof(float4) + (size_t)(2 * nwords_cap + 2) * sizeof(uint64_t) +
+           (size_t)nwords_cap * sizeof(int) + (reg ? 0 : (size_t)kNmsLdsBoxes * sizeof(float4));
 }
 
 int launch_nms(NmsParams p, int n_images, hipStream_t s)
 {
     const int nwords = ceil_div(p.total_anchors, 64);
-    p.nwords_cap = (nwords + 1) & ~1;
-    const size_t lds = nms_lds_bytes(p.total_anchors);
+    p.nwords_cap = (nwords + 3) & ~3;
+    const bool reg = p.total_anchors <= kNmsRegCap;
+    const size_t lds = nms_lds_bytes(p.total_anchors, reg);
     if (lds > 160 * 1024) {
         set_error("NMS bitmap for %d anchors does not fit LDS", p.total_anchors);
         return RFD_ERR_CAPACITY;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel),
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(n_images), dim3(kNmsThreads), lds, s, p);
+    if (reg) hipLaunchKernelGGL(nms_kernel<true>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
+    else hipLaunchKernelGGL(nms_kernel<false>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }

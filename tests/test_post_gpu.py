@@ -95,6 +95,16 @@ def test_thresholds_and_truncation(rfd, oracle):
     d.close()
 
 
+def test_large_input_uses_streaming_nms_path(rfd, oracle):
+    """1024x768 network input = 32256 anchors: beyond the register-resident NMS capacity (17408), so the
+    LDS-cache / L2 streaming variant of the kernel runs."""
+    d = rfd.RetinaFaceDetection(image_size=(1024, 768), max_batch_size=1, max_det=32256)
+    heads = helpers.make_heads(21, 1, 768, 1024, cand_rate=0.3, n_faces=200)
+    _compare(oracle, d, heads, 1, 768, 1024, np.array([0.4], np.float32))
+    assert d.stats()["candidates"] > 8000
+    d.close()
+
+
 def test_golden_fixture(rfd):
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads_128.npz"))
     d = rfd.RetinaFaceDetection(image_size=(128, 128), max_batch_size=1, max_det=400)
