@@ -179,6 +179,17 @@ def main():
     achieved = conv_flops / (conv_ms_med * 1e-3) / 1e12
     op_ms /= reps
 
+    # HBM traffic of the conv class: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes over this same command and corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py);
+    # it cannot be collected from inside the process, so the committed summary is reported (or null).
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    if BATCH == 32 and os.path.exists(tpath):
+        try:
+            traffic = float(json.load(open(tpath))["conv_igemm_hbm_bytes_per_pass"])
+        except Exception:
+            traffic = None
+
     out = None
     if rank == 0:
         value = world * BATCH * args.steps / elapsed
@@ -198,7 +209,8 @@ def main():
             "p50_ms_per_image": round(p50 / BATCH, 5),
             "stage_ms": {k: round(stats[k], 4) for k in ("ms_preprocess", "ms_network", "ms_decode", "ms_sort", "ms_nms")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per forward pass of the conv class (PMC, profiles/hbm_traffic_latest.json)",
                          "kernel": "conv_igemm_kernel (all %d implicit-GEMM conv launches of one forward pass)" % launches,
                          "flops_per_pass": conv_flops, "ms_per_pass": round(conv_ms_med, 4),
                          "avg_launch_us": round(conv_ms_med * 1e3 / max(launches, 1), 2)},

@@ -139,6 +139,9 @@ typedef struct rfd_op_desc {
     double macs; /* multiply-accumulates per image */
     int in2, layer2; /* fused 1x1 shortcut conv: + conv(tensor in2, layer2) (+ its bias); -1 = none */
     int in_affine;   /* >= 0: the input is first mapped through relu(x*scale+shift) of that layer's affine */
+    int layer_n2;    /* >= 0: a sibling conv on the same input fused along N; its output channels follow */
+    int x_coff;      /* the input is the channel slice [x_coff, x_coff + cin) of tensor `in` */
+    int y_split, y_split_add; /* output channel n goes to y_coff + n (+ y_split_add if n >= y_split) */
     int reserved[1];
 } rfd_op_desc;
 typedef struct rfd_tensor_desc {

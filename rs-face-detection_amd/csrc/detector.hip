@@ -525,6 +525,7 @@ int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
     d->res = o.res; d->relu = o.relu; d->res_up2 = o.res_up2; d->res_post = o.res_post;
     d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
     d->in2 = o.in2; d->layer2 = o.layer2; d->in_affine = o.in_affine;
+    d->layer_n2 = o.layer_n2; d->x_coff = o.x_coff; d->y_split = o.y_split; d->y_split_add = o.y_split_add;
     d->macs = g->layer_macs(idx);
     return RFD_OK;
 }

@@ -85,6 +85,8 @@ struct ConvParams {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int H2, W2, Cin2, stride2;
     int ldy, y_coff;      // primary output row pitch (channels) and channel offset (SSH concat)
+    int ldx, x_coff;      // input row pitch (channels per pixel, >= Cin) and channel offset: reads a channel slice
+    int y_split, y_split_add; // output channels >= y_split land y_split_add further (two destinations, one GEMM)
     int relu;             // relu on the primary output
     int res_up2;          // residual is half resolution: read at (ho/2, wo/2) (FPN nearest 2x)
     int res_post;         // add the residual AFTER the ReLU (FPN: relu(lateral) + upsampled)

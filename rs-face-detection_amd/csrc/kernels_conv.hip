@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     //      Offsets are BYTES relative to the tensor base (32-bit: tensors are < 4 GiB). ----
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * p.H * p.W * p.Cin * 2), 0x00020000);
+        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * p.H * p.W * p.ldx * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
             hi0[q] = ho * p.stride - p.pad;
             wi0[q] = wo * p.stride - p.pad;
             // may be "negative" (wraps) for padded rows/cols; adding a valid tap brings it back in range
-            xoff[q] = (uint32_t)(((((long long)b * p.H + hi0[q]) * p.W + wi0[q]) * p.Cin + chunk * 8) * 2);
+            xoff[q] = (uint32_t)(((((long long)b * p.H + hi0[q]) * p.W + wi0[q]) * p.ldx + p.x_coff + chunk * 8) * 2);
             if (p.Cin2)
                 xoff2[q] = (uint32_t)(((((long long)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + chunk * 8) * 2);
         } else {
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     const int kc_n = p.Cin >> 6;
     auto stage_x = [&](int slot) {
         if (kt_x < nk1) {
-            const uint32_t tap = (uint32_t)((ky * p.W + kx) * p.Cin * 2); // scalar
+            const uint32_t tap = (uint32_t)((ky * p.W + kx) * p.ldx * 2); // scalar
 #pragma unroll
             for (int q = 0; q < XP; ++q) {
                 const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                     if (p.res && p.res_post) o[k] += r[k];
                 }
                 const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + p.y_coff + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                const int nd = n + p.y_coff + (n >= p.y_split ? p.y_split_add : 0);
+                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + nd) = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             if (p.y2) {
                 float o[8];
@@ -368,7 +369,7 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         set_error("conv: the input affine is only defined for un-padded 1x1 convs with Cin <= 2048");
         return RFD_ERR_INVALID_ARG;
     }
-    if ((size_t)p.B * p.H * p.W * p.Cin * 2 >= 0xfffffff0ull || (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 >= 0xfffffff0ull) {
+    if ((size_t)p.B * p.H * p.W * p.ldx * 2 >= 0xfffffff0ull || (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 >= 0xfffffff0ull) {
         set_error("conv: an input tensor of %zu bytes exceeds the 4 GiB buffer-addressing limit; lower max_batch_size",
                   (size_t)p.B * p.H * p.W * p.Cin * 2);
         return RFD_ERR_CAPACITY;
@@ -384,6 +385,7 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         if (p.force_tile == 1 || p.in_scale) return launch_conv_cfg<128, 128, 2, 2, 2>(p, s);
         return launch_conv_cfg<128, 128, 2, 2, 3>(p, s);
     }
+    if (p.Cout % 192 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 192, 2, 2, 2>(p, s); // fused SSH pair
     // 128x64: the 2-slot ring keeps 3 workgroups per CU, which measured faster than a deeper ring at 2
     if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1, 2>(p, s);
     return launch_conv_cfg<128, 32, 4, 1, 2>(p, s);

@@ -17,7 +17,8 @@ struct Layer {
     size_t w_off;   // element offset into the bf16 weight buffer (first column of this layer's block)
     size_t ldw;     // device row pitch in elements (> kh*kw*cin when a shortcut conv shares the rows)
     size_t w_elems; // device elements (conv0 is stored K-padded: 64*7*32)
-    size_t b_off;   // float offset of bias; scale2 at b_off+cout, shift2 at b_off+2*cout
+    size_t b_off;   // float offset of the bias [cout] (consecutive layers are contiguous: N-fused convs)
+    size_t a_off;   // float offset of the post-add affine: scale [cout] then shift [cout] (has_affine only)
 };
 
 enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2 };
@@ -28,6 +29,9 @@ struct Op {
     int in, out, out2, outf, res; // tensor ids, -1 = none
     int in2, layer2;              // fused second K segment (1x1 shortcut conv on tensor in2), -1 = none
     int in_affine;                // layer whose post-add affine (+ReLU) is applied to this op's INPUT, -1 = none
+    int layer_n2;                 // second conv fused along N (same input and geometry; its rows follow), -1 = none
+    int x_coff;                   // the input is the channel slice [x_coff, x_coff+cin) of tensor `in`
+    int y_split, y_split_add;     // output channels >= y_split are stored y_split_add channels further
     int relu, res_up2, res_post, head_softmax, y_coff;
 };
 
@@ -46,7 +50,7 @@ struct Graph {
     std::vector<TensorDesc> tensors;
     int input = -1;        // NHWC4 bf16 network input
     int heads[3] = {-1, -1, -1}; // f32 [h][w][32] per level (stride 32,16,8)
-    size_t w_total = 0, b_total = 0;
+    size_t w_total = 0, b_total = 0, a_total = 0;
     std::vector<size_t> buffer_bytes_per_image; // workspace plan
 
     int build(int backbone, int net_w, int net_h);

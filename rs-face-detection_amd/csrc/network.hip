@@ -37,7 +37,9 @@ int Graph::add_layer(const std::string &name, int cin, int cout, int k, int stri
     }
     w_total += (L.w_elems + 63) & ~(size_t)63; // keep every layer 128-byte aligned
     L.b_off = b_total;
-    b_total += (size_t)3 * cout;
+    b_total += (size_t)cout;
+    L.a_off = a_total;
+    if (has_affine) a_total += (size_t)2 * cout;
     layers.push_back(L);
     return (int)layers.size() - 1;
 }
@@ -47,6 +49,7 @@ int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int
     Op o;
     o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
     o.in2 = -1; o.layer2 = -1; o.in_affine = -1;
+    o.layer_n2 = -1; o.x_coff = 0; o.y_split = 1 << 30; o.y_split_add = 0;
     o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
     ops.push_back(o);
     return (int)ops.size() - 1;
@@ -63,12 +66,12 @@ void Graph::build_r50()
     const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1);
     const int t_c0 = add_tensor(64, H / 2, W / 2);
     {
-        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, -1, -1, -1, 1, 0, 0, 0, 0};
+        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, -1, -1, -1, 1, 0, 0, 0, 0};
+        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
@@ -143,24 +146,36 @@ void Graph::build_r50()
     const int p1 = add_tensor(256, T(c1).H, T(c1).W);
     add_conv(ag1, p1pre, p1, 1);
 
-    // SSH context module + fused heads per level, order = reference slot order 32,16,8
+    // SSH context module + fused heads per level, order = reference slot order 32,16,8.
+    // One 384-channel buffer O = [b1 0:128 | b2 128:192 | b3 192:256 | tc 256:320 | td 320:384]; sibling convs
+    // that share an input run as ONE GEMM along N:  {conv1, ctx1}(f) -> b1 | tc ;  {ctx2, ctx3a}(tc) -> b2 | td ;
+    // ctx3b(td) -> b3 ;  heads read the concat O[:, 0:256].  (All five carry the post-concat ReLU.)
     const int feats[3] = {p3, p2, p1};
     for (int l = 0; l < 3; ++l) {
         const int f = feats[l], fh = T(f).H, fw = T(f).W, st = kStrides[l];
         char nm[64];
-        const int o = add_tensor(256, fh, fw);
+        const int o = add_tensor(384, fh, fw);
         snprintf(nm, sizeof nm, "ssh%d_conv1", st);
-        add_conv(add_layer(nm, 256, 128, 3, 1, 1, 1.0f, 0), f, o, 1);
+        const int la = add_layer(nm, 256, 128, 3, 1, 1, 1.0f, 0);
         snprintf(nm, sizeof nm, "ssh%d_ctx1", st);
-        const int tc = add_tensor(64, fh, fw);
-        add_conv(add_layer(nm, 256, 64, 3, 1, 1, 1.0f, 0), f, tc, 1);
+        const int lb = add_layer(nm, 256, 64, 3, 1, 1, 1.0f, 0);
+        {
+            Op &A = ops[add_conv(la, f, o, 1)];
+            A.layer_n2 = lb; A.y_split = 128; A.y_split_add = 128;
+        }
         snprintf(nm, sizeof nm, "ssh%d_ctx2", st);
-        ops[add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), tc, o, 1)].y_coff = 128;
+        const int lc = add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0);
         snprintf(nm, sizeof nm, "ssh%d_ctx3a", st);
-        const int td = add_tensor(64, fh, fw);
-        add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), tc, td, 1);
+        const int ld = add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0);
+        {
+            Op &B = ops[add_conv(lc, o, o, 1)];
+            B.layer_n2 = ld; B.x_coff = 256; B.y_coff = 128; B.y_split = 64; B.y_split_add = 128;
+        }
         snprintf(nm, sizeof nm, "ssh%d_ctx3b", st);
-        ops[add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), td, o, 1)].y_coff = 192;
+        {
+            Op &C = ops[add_conv(add_layer(nm, 64, 64, 3, 1, 1, 1.0f, 0), o, o, 1)];
+            C.x_coff = 320; C.y_coff = 192;
+        }
         snprintf(nm, sizeof nm, "head%d", st);
         heads[l] = add_tensor(32, fh, fw, 1);
         ops[add_conv(add_layer(nm, 256, 32, 1, 1, 0, 1.0f, 0), o, -1, 0, -1, -1, heads[l])].head_softmax = 1;
@@ -245,6 +260,7 @@ double Graph::layer_macs(int i) const
     const int t = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
     double m = (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
     if (o.layer2 >= 0) m += (double)tensors[t].H * tensors[t].W * L.cout * layers[o.layer2].cin;
+    if (o.layer_n2 >= 0) m += (double)tensors[t].H * tensors[t].W * layers[o.layer_n2].cout * L.kh * L.kw * L.cin;
     return m;
 }
 
@@ -263,7 +279,7 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     RFD_TRY(g.build(backbone, net_w, net_h));
     max_batch = max_batch_;
     RFD_HIP(hipMalloc((void **)&d_w, g.w_total * sizeof(bf16_t)));
-    RFD_HIP(hipMalloc((void **)&d_b, g.b_total * sizeof(float)));
+    RFD_HIP(hipMalloc((void **)&d_b, (g.b_total + g.a_total) * sizeof(float))); // biases, then affines
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
@@ -408,8 +424,8 @@ int Network::set_affine(int idx, const float *scale, const float *shift, hipStre
 {
     if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
-    RFD_HIP(hipMemcpyAsync(d_b + L.b_off + L.cout, scale, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
-    RFD_HIP(hipMemcpyAsync(d_b + L.b_off + 2 * L.cout, shift, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipMemcpyAsync(d_b + g.b_total + L.a_off, scale, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipMemcpyAsync(d_b + g.b_total + L.a_off + L.cout, shift, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
     RFD_HIP(hipStreamSynchronize(s));
     return RFD_OK;
 }
@@ -418,8 +434,8 @@ int Network::get_affine(int idx, float *scale, float *shift, hipStream_t s)
 {
     if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
-    RFD_HIP(hipMemcpyAsync(scale, d_b + L.b_off + L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
-    RFD_HIP(hipMemcpyAsync(shift, d_b + L.b_off + 2 * L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+    RFD_HIP(hipMemcpyAsync(scale, d_b + g.b_total + L.a_off, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+    RFD_HIP(hipMemcpyAsync(shift, d_b + g.b_total + L.a_off + L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
     RFD_HIP(hipStreamSynchronize(s));
     return RFD_OK;
 }
@@ -445,7 +461,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
                                  (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
         } else if (o.kind == OP_POOL) {
             RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
-                                        d_b + L.b_off + L.cout, d_b + L.b_off + 2 * L.cout, B, tin.H, tin.W,
+                                        d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout, B, tin.H, tin.W,
                                         tin.C, s));
         } else {
             const int tout = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
@@ -466,18 +482,20 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
             }
             if (o.in_affine >= 0) {
                 const Layer &La = g.layers[o.in_affine];
-                p.in_scale = d_b + La.b_off + La.cout;
-                p.in_shift = d_b + La.b_off + 2 * La.cout;
+                p.in_scale = d_b + g.b_total + La.a_off;
+                p.in_shift = d_b + g.b_total + La.a_off + La.cout;
             }
-            p.scale2 = d_b + L.b_off + L.cout;
-            p.shift2 = d_b + L.b_off + 2 * L.cout;
+            p.scale2 = d_b + g.b_total + L.a_off;
+            p.shift2 = d_b + g.b_total + L.a_off + L.cout;
             p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out) : nullptr;
             p.y2 = o.out2 >= 0 ? (bf16_t *)tensor_ptr(o.out2) : nullptr;
             p.yf = o.outf >= 0 ? (float *)tensor_ptr(o.outf) : nullptr;
-            p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin; p.Cout = L.cout;
+            p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin;
+            p.Cout = L.cout + (o.layer_n2 >= 0 ? g.layers[o.layer_n2].cout : 0); // N-fused sibling: its rows follow
+            p.ldx = tin.C; p.x_coff = o.x_coff; p.y_split = o.y_split; p.y_split_add = o.y_split_add;
             p.KH = L.kh; p.KW = L.kw; p.stride = L.stride; p.pad = L.pad;
             p.Ho = g.tensors[tout].H; p.Wo = g.tensors[tout].W;
-            p.ldy = o.out >= 0 ? g.tensors[o.out].C : L.cout;
+            p.ldy = o.out >= 0 ? g.tensors[o.out].C : p.Cout;
             p.y_coff = o.y_coff;
             p.relu = o.relu; p.res_up2 = o.res_up2; p.res_post = o.res_post; p.head_softmax = o.head_softmax;
             RFD_TRY(launch_conv(p, s));

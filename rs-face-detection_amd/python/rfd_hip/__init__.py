@@ -71,7 +71,8 @@ class rfd_op_desc(C.Structure):
                 ("out2", C.c_int), ("outf", C.c_int), ("res", C.c_int), ("relu", C.c_int),
                 ("res_up2", C.c_int), ("res_post", C.c_int), ("head_softmax", C.c_int),
                 ("y_coff", C.c_int), ("macs", C.c_double), ("in2", C.c_int), ("layer2", C.c_int),
-                ("in_affine", C.c_int), ("reserved", C.c_int * 1)]
+                ("in_affine", C.c_int), ("layer_n2", C.c_int), ("x_coff", C.c_int), ("y_split", C.c_int),
+                ("y_split_add", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class rfd_tensor_desc(C.Structure):

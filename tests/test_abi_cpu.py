@@ -36,7 +36,9 @@ def test_graph_matches_survey_appendix_b(rfd):
     convs = [o for o in g.ops if o.kind in (0, 2)]
     heads = [o for o in g.ops if o.head_softmax]
     fused_sc = [o for o in g.ops if o.layer2 >= 0]     # 4 shortcut convs ride in their conv3's GEMM
-    assert len(convs) + 2 * len(heads) + len(fused_sc) == 82  # 9 head convs run as 3 fused N=32 GEMMs
+    fused_n = [o for o in g.ops if o.layer_n2 >= 0]    # 6 SSH sibling pairs run as one GEMM along N
+    assert len(convs) + 2 * len(heads) + len(fused_sc) + len(fused_n) == 82  # 9 head convs = 3 fused N=32 GEMMs
+    assert len(fused_n) == 6
     assert len(fused_sc) == 4 and g.num_layers == 76
     assert sorted(t.head_level for t in g.tensors if t.head_level) == [1, 2, 3]
     hl = {t.head_level: (t.height, t.width, t.channels) for t in g.tensors if t.head_level}
@@ -53,9 +55,16 @@ def test_graph_plan_has_no_aliasing(rfd):
     # tensors that share a buffer must have disjoint live ranges: an op never reads and writes one buffer
     for o in g.ops:
         outs = [t for t in (o.out, o.out2, o.outf) if t >= 0]
-        ins = [t for t in (o.in_, o.res) if t >= 0]
+        ins = [t for t in (o.in_, o.in2, o.res) if t >= 0]
         ob = [g.tensors[t].buffer for t in outs]
         assert len(set(ob)) == len(ob)
+        if o.out == o.in_:  # SSH: reads one channel slice of the concat buffer, writes a disjoint one
+            L = g.layers[o.layer]
+            nout = L.cout + (g.layers[o.layer_n2].cout if o.layer_n2 >= 0 else 0)
+            rd = set(range(o.x_coff, o.x_coff + L.cin))
+            wr = {o.y_coff + n + (o.y_split_add if n >= o.y_split else 0) for n in range(nout)}
+            assert not rd & wr
+            continue
         assert not set(ob) & {g.tensors[t].buffer for t in ins}
 
 

@@ -35,6 +35,8 @@ class TorchRef:
         o = g.ops[i]
         L = g.layers[o.layer]
         x = tensors[o.in_]
+        if o.kind == 2 and x.shape[1] != L.cin:  # the input is a channel slice of a wider tensor
+            x = x[:, o.x_coff:o.x_coff + L.cin]
         if o.kind == 0:  # conv0 7x7/2 on R,G,B (+ zero 4th channel) + bias + relu
             v = F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
             tensors[o.out] = bf16r(F.relu(v))
@@ -47,7 +49,11 @@ class TorchRef:
         if o.in_affine >= 0:  # BN+ReLU of the producer unit, applied to this conv's input (rounded to bf16)
             s, t = self.aff[o.in_affine]
             x = bf16r(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
-        v = F.conv2d(x, self.w[o.layer], self.b[o.layer], stride=L.stride, padding=L.pad)
+        wgt, bias = self.w[o.layer], self.b[o.layer]
+        if o.layer_n2 >= 0:  # sibling conv on the same input fused along N: its output channels follow
+            wgt = torch.cat([wgt, self.w[o.layer_n2]], 0)
+            bias = torch.cat([bias, self.b[o.layer_n2]], 0)
+        v = F.conv2d(x, wgt, bias, stride=L.stride, padding=L.pad)
         if o.layer2 >= 0:  # the 1x1 shortcut conv fused as a second K segment of the same GEMM
             L2 = g.layers[o.layer2]
             v = v + F.conv2d(tensors[o.in2], self.w[o.layer2], self.b[o.layer2], stride=L2.stride)
@@ -64,10 +70,14 @@ class TorchRef:
                 y = y + r
             y = bf16r(y)
             td = g.tensors[o.out]
-            if td.channels != L.cout:  # SSH concat: write a channel slice
+            nout = y.shape[1]
+            if td.channels != nout:  # SSH concat buffer: channel n -> y_coff + n (+ y_split_add if n >= y_split)
                 if o.out not in tensors:
                     tensors[o.out] = torch.zeros(x.shape[0], td.channels, td.height, td.width)
-                tensors[o.out][:, o.y_coff:o.y_coff + L.cout] = y
+                s = min(o.y_split, nout)
+                tensors[o.out][:, o.y_coff:o.y_coff + s] = y[:, :s]
+                if s < nout:
+                    tensors[o.out][:, o.y_coff + o.y_split_add + s:o.y_coff + o.y_split_add + nout] = y[:, s:]
             else:
                 tensors[o.out] = y
         if o.out2 >= 0:
