@@ -131,7 +131,8 @@ typedef struct rfd_layer_desc {
     int reserved[4];
 } rfd_layer_desc;
 typedef struct rfd_op_desc {
-    int kind;  /* 0: conv0 7x7/2 + bias + ReLU, 1: maxpool 3x3/2 (+ affine + ReLU), 2: conv */
+    int kind;  /* 0: conv0 7x7/2 + bias + ReLU, 1: maxpool 3x3/2 (+ affine + ReLU), 2: conv,
+                  3: fused stem = kind 0 then kind 1 (conv0 result rounded to bf16 in between) */
     int layer; /* weights used (kind 1: the layer whose affine is applied) */
     int in, out, out2, outf, res; /* tensor ids, -1 = none: out = bf16 result, out2 = relu(affine(v)),
                                      outf = f32 result (heads), res = residual input */

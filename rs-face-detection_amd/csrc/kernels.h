@@ -97,6 +97,9 @@ int launch_conv(const ConvParams &p, hipStream_t s);
 // conv0: 7x7 stride 2 pad 3 on the NHWC4 input, fused bias + ReLU -> [B][H/2][W/2][64]
 int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H,
                  int W, hipStream_t s);
+// fused stem: conv0 (7x7/2 + bias + ReLU) -> 3x3/2 max pool -> affine + ReLU, NHWC4 in, [B][H/4][W/4][64] out
+int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const float *scale, const float *shift,
+                bf16_t *y, int B, int H, int W, hipStream_t s);
 // 3x3 stride 2 pad 1 max pool, NHWC bf16
 // optional fused per-channel affine + ReLU on the pooled value (scale/shift may be null)
 int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const float *shift, int B, int H,

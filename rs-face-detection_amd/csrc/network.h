@@ -21,7 +21,7 @@ struct Layer {
     size_t a_off;   // float offset of the post-add affine: scale [cout] then shift [cout] (has_affine only)
 };
 
-enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2 };
+enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2, OP_STEM = 3 };
 
 struct Op {
     int kind;

@@ -64,14 +64,10 @@ void Graph::build_r50()
     const int H = net_h, W = net_w;
     input = add_tensor(4, H, W);
     const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1);
-    const int t_c0 = add_tensor(64, H / 2, W / 2);
-    {
-        Op o{OP_CONV0, l0, input, t_c0, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
-        ops.push_back(o);
-    }
+    // stem: conv0 + BN + ReLU + max pool + BN1 + ReLU as ONE kernel (the 320x320x64 conv0 activation stays on chip)
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_POOL, l0, t_c0, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
+        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
@@ -257,6 +253,7 @@ double Graph::layer_macs(int i) const
     const Op &o = ops[i];
     if (o.kind == OP_POOL) return 0.0;
     const Layer &L = layers[o.layer];
+    if (o.kind == OP_STEM) return (double)(net_h / 2) * (net_w / 2) * L.cout * L.kh * L.kw * L.cin;
     const int t = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
     double m = (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
     if (o.layer2 >= 0) m += (double)tensors[t].H * tensors[t].W * L.cout * layers[o.layer2].cin;
@@ -459,6 +456,9 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         if (o.kind == OP_CONV0) {
             RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off,
                                  (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+        } else if (o.kind == OP_STEM) {
+            RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
+                                d_b + g.b_total + L.a_off + L.cout, (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
         } else if (o.kind == OP_POOL) {
             RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
                                         d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout, B, tin.H, tin.W,

@@ -33,7 +33,7 @@ def test_exports_only_the_c_abi(rfd):
 def test_graph_matches_survey_appendix_b(rfd):
     g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
     assert abs(g.macs - 44.2646528e9) < 1e3          # 44.265 GMAC / image
-    convs = [o for o in g.ops if o.kind in (0, 2)]
+    convs = [o for o in g.ops if o.kind in (0, 2, 3)]
     heads = [o for o in g.ops if o.head_softmax]
     fused_sc = [o for o in g.ops if o.layer2 >= 0]     # 4 shortcut convs ride in their conv3's GEMM
     fused_n = [o for o in g.ops if o.layer_n2 >= 0]    # 6 SSH sibling pairs run as one GEMM along N

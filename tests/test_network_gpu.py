@@ -59,7 +59,7 @@ def test_every_op_in_isolation(rfd, net, tile):
             continue
         tens = {}
         tin = g.tensors[o.in_]
-        if o.kind == 0:
+        if o.kind in (0, 3):
             x = rng.integers(0, 256, size=(n, 4, tin.height, tin.width)).astype(np.float32)
             x[:, 3] = 0
             tens[o.in_] = torch.from_numpy(x)

@@ -41,6 +41,11 @@ class TorchRef:
             v = F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
             tensors[o.out] = bf16r(F.relu(v))
             return
+        if o.kind == 3:  # fused stem: conv0 + bias + relu (bf16) -> maxpool 3x3/2 pad 1 -> affine + relu
+            v = bf16r(F.relu(F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)))
+            s, t = self.aff[o.layer]
+            tensors[o.out] = bf16r(F.relu(F.max_pool2d(v, 3, 2, 1) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+            return
         if o.kind == 1:  # maxpool 3x3/2 pad 1, then affine + relu
             v = F.max_pool2d(x, 3, 2, 1)
             s, t = self.aff[o.layer]
