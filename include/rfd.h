@@ -128,11 +128,13 @@ typedef struct rfd_layer_desc {
     char name[64];
     int cin, cout, kh, kw, stride, pad;
     int has_affine; /* per-channel scale/shift + ReLU applied after the residual add (or the pool) */
-    int reserved[4];
+    int kind;       /* 0 conv, 1 depthwise 3x3 (cin = 1, cout = channels; weights [C][3][3][1]), 2 first 3x3/2, 3 conv0 7x7/2 */
+    int reserved[3];
 } rfd_layer_desc;
 typedef struct rfd_op_desc {
     int kind;  /* 0: conv0 7x7/2 + bias + ReLU, 1: maxpool 3x3/2 (+ affine + ReLU), 2: conv,
-                  3: fused stem = kind 0 then kind 1 (conv0 result rounded to bf16 in between) */
+                  3: fused stem = kind 0 then kind 1 (conv0 result rounded to bf16 in between),
+                  4: depthwise 3x3 + bias + ReLU, 5: first 3x3/2 conv (3 input channels) + bias + ReLU */
     int layer; /* weights used (kind 1: the layer whose affine is applied) */
     int in, out, out2, outf, res; /* tensor ids, -1 = none: out = bf16 result, out2 = relu(affine(v)),
                                      outf = f32 result (heads), res = residual input */
@@ -143,12 +145,13 @@ typedef struct rfd_op_desc {
     int layer_n2;    /* >= 0: a sibling conv on the same input fused along N; its output channels follow */
     int x_coff;      /* the input is the channel slice [x_coff, x_coff + cin) of tensor `in` */
     int y_split, y_split_add; /* output channel n goes to y_coff + n (+ y_split_add if n >= y_split) */
-    int reserved[1];
+    int n_valid;     /* only output channels < n_valid are stored */
 } rfd_op_desc;
 typedef struct rfd_tensor_desc {
-    int channels, height, width;
+    int channels, height, width; /* channels = device channels: channels_logical zero-padded (to 64) */
     int is_f32, buffer, is_input, head_level; /* head_level: 1,2,3 = stride 32,16,8 head tensor */
-    int reserved[4];
+    int channels_logical;
+    int reserved[3];
 } rfd_tensor_desc;
 RFD_API int rfd_graph_create(int backbone, int image_w, int image_h, rfd_graph **out);
 RFD_API void rfd_graph_destroy(rfd_graph *g);

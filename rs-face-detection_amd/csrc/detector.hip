@@ -512,6 +512,7 @@ int rfd_graph_layer(const rfd_graph *gg, int idx, rfd_layer_desc *d)
     snprintf(d->name, sizeof d->name, "%s", L.name.c_str());
     d->cin = L.cin; d->cout = L.cout; d->kh = L.kh; d->kw = L.kw; d->stride = L.stride; d->pad = L.pad;
     d->has_affine = L.has_affine;
+    d->kind = L.kind;
     return RFD_OK;
 }
 int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
@@ -526,6 +527,7 @@ int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
     d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
     d->in2 = o.in2; d->layer2 = o.layer2; d->in_affine = o.in_affine;
     d->layer_n2 = o.layer_n2; d->x_coff = o.x_coff; d->y_split = o.y_split; d->y_split_add = o.y_split_add;
+    d->n_valid = o.n_valid;
     d->macs = g->layer_macs(idx);
     return RFD_OK;
 }
@@ -536,7 +538,8 @@ int rfd_graph_tensor(const rfd_graph *gg, int idx, rfd_tensor_desc *d)
     RFD_CHECK_ARG(idx >= 0 && idx < (int)g->tensors.size(), "tensor index out of range");
     const TensorDesc &t = g->tensors[idx];
     memset(d, 0, sizeof *d);
-    d->channels = t.C; d->height = t.H; d->width = t.W; d->is_f32 = t.is_f32; d->buffer = t.buffer;
+    d->channels = t.C; d->channels_logical = t.C_logical; d->height = t.H; d->width = t.W; d->is_f32 = t.is_f32;
+    d->buffer = t.buffer;
     d->is_input = idx == g->input;
     for (int l = 0; l < 3; ++l)
         if (g->heads[l] == idx) d->head_level = l + 1;

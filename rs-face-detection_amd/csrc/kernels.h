@@ -87,6 +87,7 @@ struct ConvParams {
     int ldy, y_coff;      // primary output row pitch (channels) and channel offset (SSH concat)
     int ldx, x_coff;      // input row pitch (channels per pixel, >= Cin) and channel offset: reads a channel slice
     int y_split, y_split_add; // output channels >= y_split land y_split_add further (two destinations, one GEMM)
+    int n_valid;          // primary-output channels >= n_valid (zero-padded weight rows) are not stored
     int relu;             // relu on the primary output
     int res_up2;          // residual is half resolution: read at (ho/2, wo/2) (FPN nearest 2x)
     int res_post;         // add the residual AFTER the ReLU (FPN: relu(lateral) + upsampled)
@@ -100,6 +101,11 @@ int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y
 // fused stem: conv0 (7x7/2 + bias + ReLU) -> 3x3/2 max pool -> affine + ReLU, NHWC4 in, [B][H/4][W/4][64] out
 int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const float *scale, const float *shift,
                 bf16_t *y, int B, int H, int W, hipStream_t s);
+// MobileNet-0.25 helpers: first 3x3/2 conv (3 -> 8 real channels, output padded to Cd) and depthwise 3x3
+int launch_first3x3(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W, int Cd,
+                    hipStream_t s);
+int launch_dwconv3x3(const bf16_t *x, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W, int C,
+                     int stride, hipStream_t s);
 // 3x3 stride 2 pad 1 max pool, NHWC bf16
 // optional fused per-channel affine + ReLU on the pooled value (scale/shift may be null)
 int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const float *shift, int B, int H,

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                     for (int k = 0; k < 8; ++k) v[k] += r[k];
                 }
             }
-            if (p.y) {
+            if (p.y && n < p.n_valid) {
                 float o[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -668,6 +668,117 @@ int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const fl
     const long long total = (long long)B * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, scale,
                        shift, B, H, W, C, Ho, Wo);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MobileNet-0.25 backbone helpers (memory-bound byte work, no MFMA):
+//   first3x3_kernel : 3x3 stride-2 pad-1 conv on the NHWC4 input, 3 -> 8 channels (+bias, ReLU); the output
+//                     tensor is channel-padded to 64 (zeros) so that every later 1x1/3x3 conv can run on the
+//                     MFMA implicit-GEMM kernel with K a multiple of 64.
+//   dwconv3x3_kernel: depthwise 3x3 (stride 1 or 2, pad 1) + bias + ReLU, NHWC, 8 channels (16 B) per thread,
+//                     weights [9][C] bf16.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) first3x3_kernel(const bf16_t *__restrict__ x4, const bf16_t *__restrict__ w, // [8][3][3][4]
+                                                       const float *__restrict__ bias, bf16_t *__restrict__ y, int B,
+                                                       int H, int W, int Ho, int Wo, int Cd)
+{
+    __shared__ float ws[8 * 36];
+    for (int i = threadIdx.x; i < 8 * 36; i += 256) ws[i] = bf16_bits_to_f32(w[i]);
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * Ho * Wo) return;
+    const int wo = (int)(i % Wo);
+    const int ho = (int)((i / Wo) % Ho);
+    const int b = (int)(i / ((long long)Wo * Ho));
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = bias[c];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hi = 2 * ho - 1 + ky;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int wi = 2 * wo - 1 + kx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint2 p = reinterpret_cast<const uint2 *>(x4)[((long long)b * H + hi) * W + wi];
+            const float r = bf16_bits_to_f32(p.x & 0xffffu), g = bf16_bits_to_f32(p.x >> 16), bl = bf16_bits_to_f32(p.y & 0xffffu);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float *wc = ws + c * 36 + (ky * 3 + kx) * 4;
+                acc[c] += r * wc[0] + g * wc[1] + bl * wc[2];
+            }
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(y + i * Cd);
+    const uint2 lo = pack_bf16x4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    const uint2 hi2 = pack_bf16x4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+    dst[0] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+    for (int k = 1; k < Cd / 8; ++k) dst[k] = make_uint4(0, 0, 0, 0);
+}
+
+int launch_first3x3(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W, int Cd,
+                    hipStream_t s)
+{
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo;
+    hipLaunchKernelGGL(first3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x4, w, bias, y, B, H, W,
+                       Ho, Wo, Cd);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+__global__ void __launch_bounds__(256) dwconv3x3_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ w, // [9][C]
+                                                        const float *__restrict__ bias, bf16_t *__restrict__ y, int B,
+                                                        int H, int W, int C, int Ho, int Wo, int stride)
+{
+    const int cg = C >> 3;
+    const long long total = (long long)B * Ho * Wo * cg;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg) * 8;
+    long long pix = i / cg;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float acc[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + c), b1 = *reinterpret_cast<const float4 *>(bias + c + 4);
+        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hi = ho * stride - 1 + ky;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int wi = wo * stride - 1 + kx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + (((long long)b * H + hi) * W + wi) * C + c);
+            const uint4 k = *reinterpret_cast<const uint4 *>(w + (ky * 3 + kx) * C + c);
+            const uint32_t vu[4] = {v.x, v.y, v.z, v.w}, ku[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += bf16_bits_to_f32(vu[e] & 0xffffu) * bf16_bits_to_f32(ku[e] & 0xffffu);
+                acc[2 * e + 1] += bf16_bits_to_f32(vu[e] >> 16) * bf16_bits_to_f32(ku[e] >> 16);
+            }
+        }
+    }
+    const uint2 lo = pack_bf16x4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    const uint2 hi2 = pack_bf16x4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+    *reinterpret_cast<uint4 *>(y + i * 8) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+}
+
+int launch_dwconv3x3(const bf16_t *x, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W, int C,
+                     int stride, hipStream_t s)
+{
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, y, B, H, W,
+                       C, Ho, Wo, stride);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }

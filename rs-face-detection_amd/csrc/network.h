@@ -9,9 +9,13 @@
 
 namespace rfd {
 
+enum LayerKind { LK_CONV = 0, LK_DEPTHWISE = 1, LK_FIRST3X3 = 2, LK_CONV0 = 3 };
+
 struct Layer {
     std::string name;
-    int cin, cout, kh, kw, stride, pad;
+    int cin, cout, kh, kw, stride, pad; // logical shape (depthwise: cin = 1, cout = channels)
+    int kind;         // LayerKind
+    int cin_d, cout_d; // device shape: channels zero-padded to the granularity of the MFMA conv kernel
     int has_affine; // per-channel scale2/shift2 (the BN+ReLU that follows a residual add / the pool)
     float gain;     // synthetic-init gain on the He std
     size_t w_off;   // element offset into the bf16 weight buffer (first column of this layer's block)
@@ -21,7 +25,7 @@ struct Layer {
     size_t a_off;   // float offset of the post-add affine: scale [cout] then shift [cout] (has_affine only)
 };
 
-enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2, OP_STEM = 3 };
+enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2, OP_STEM = 3, OP_DW = 4, OP_FIRST = 5 };
 
 struct Op {
     int kind;
@@ -32,11 +36,13 @@ struct Op {
     int layer_n2;                 // second conv fused along N (same input and geometry; its rows follow), -1 = none
     int x_coff;                   // the input is the channel slice [x_coff, x_coff+cin) of tensor `in`
     int y_split, y_split_add;     // output channels >= y_split are stored y_split_add channels further
+    int n_valid;                  // only output channels < n_valid are stored (padded weight rows)
     int relu, res_up2, res_post, head_softmax, y_coff;
 };
 
 struct TensorDesc {
-    int C, H, W;
+    int C, H, W;    // C = device channels (>= C_logical, zero padded)
+    int C_logical;
     int is_f32;
     int buffer;     // workspace buffer id (assigned by plan())
     int first, last; // op index range in which the tensor is live
@@ -60,9 +66,11 @@ struct Graph {
   private:
     int add_tensor(int C, int H, int W, int f32 = 0);
     int add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
-                  int has_affine, int extra_k = 0, int parent = -1, int col_off = 0);
+                  int has_affine, int extra_k = 0, int parent = -1, int col_off = 0, int kind = LK_CONV,
+                  int cout_dev = 0);
     int add_conv(int layer, int in, int out, int relu, int res = -1, int out2 = -1, int outf = -1);
     void build_r50();
+    void build_mnet025();
     void plan();
 };
 

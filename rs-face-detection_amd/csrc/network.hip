@@ -13,7 +13,9 @@ namespace rfd {
 int Graph::add_tensor(int C, int H, int W, int f32)
 {
     TensorDesc t;
-    t.C = C; t.H = H; t.W = W; t.is_f32 = f32; t.buffer = -1; t.first = 1 << 30; t.last = -1;
+    t.C_logical = C;
+    t.C = (f32 || C == 4 || C % 64 == 0) ? C : (C + 63) / 64 * 64; // bf16 activations: K of every consumer is a multiple of 64
+    t.H = H; t.W = W; t.is_f32 = f32; t.buffer = -1; t.first = 1 << 30; t.last = -1;
     tensors.push_back(t);
     return (int)tensors.size() - 1;
 }
@@ -21,25 +23,29 @@ int Graph::add_tensor(int C, int H, int W, int f32)
 // extra_k > 0: reserve extra_k more columns per row for a fused shortcut conv; parent >= 0: this layer
 // lives in those columns (at col_off) of layer `parent` and allocates nothing.
 int Graph::add_layer(const std::string &name, int cin, int cout, int k, int stride, int pad, float gain,
-                     int has_affine, int extra_k, int parent, int col_off)
+                     int has_affine, int extra_k, int parent, int col_off, int kind, int cout_dev)
 {
     Layer L;
     L.name = name; L.cin = cin; L.cout = cout; L.kh = k; L.kw = k; L.stride = stride; L.pad = pad;
-    L.gain = gain; L.has_affine = has_affine;
+    L.gain = gain; L.has_affine = has_affine; L.kind = kind;
+    L.cin_d = kind == LK_CONV ? (cin + 63) / 64 * 64 : cin;
+    L.cout_d = cout_dev ? cout_dev : cout;
     if (parent >= 0) {
         L.w_off = layers[parent].w_off + col_off;
         L.ldw = layers[parent].ldw;
         L.w_elems = 0;
     } else {
         L.w_off = w_total;
-        L.ldw = (k == 7 && cin == 3) ? 7 * 32 : (size_t)k * k * cin + extra_k;
-        L.w_elems = (size_t)cout * L.ldw;
+        if (kind == LK_CONV0) { L.ldw = 7 * 32; L.w_elems = (size_t)cout * L.ldw; }
+        else if (kind == LK_FIRST3X3) { L.ldw = 36; L.w_elems = (size_t)cout * 36; }        // [cout][3][3][4]
+        else if (kind == LK_DEPTHWISE) { L.ldw = L.cout_d; L.w_elems = (size_t)9 * L.cout_d; } // [9][C]
+        else { L.ldw = (size_t)k * k * L.cin_d + extra_k; L.w_elems = (size_t)L.cout_d * L.ldw; }
     }
     w_total += (L.w_elems + 63) & ~(size_t)63; // keep every layer 128-byte aligned
     L.b_off = b_total;
-    b_total += (size_t)cout;
+    b_total += (size_t)L.cout_d;
     L.a_off = a_total;
-    if (has_affine) a_total += (size_t)2 * cout;
+    if (has_affine) a_total += (size_t)2 * L.cout_d;
     layers.push_back(L);
     return (int)layers.size() - 1;
 }
@@ -49,7 +55,7 @@ int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int
     Op o;
     o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
     o.in2 = -1; o.layer2 = -1; o.in_affine = -1;
-    o.layer_n2 = -1; o.x_coff = 0; o.y_split = 1 << 30; o.y_split_add = 0;
+    o.layer_n2 = -1; o.x_coff = 0; o.y_split = 1 << 30; o.y_split_add = 0; o.n_valid = 1 << 30;
     o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
     ops.push_back(o);
     return (int)ops.size() - 1;
@@ -63,11 +69,11 @@ void Graph::build_r50()
 {
     const int H = net_h, W = net_w;
     input = add_tensor(4, H, W);
-    const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1);
+    const int l0 = add_layer("conv0", 3, 64, 7, 2, 3, 1.0f / 128.0f, 1, 0, -1, 0, LK_CONV0);
     // stem: conv0 + BN + ReLU + max pool + BN1 + ReLU as ONE kernel (the 320x320x64 conv0 activation stays on chip)
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1, 0, 0, 0, 0};
+        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
@@ -178,6 +184,74 @@ void Graph::build_r50()
     }
 }
 
+// RetinaFace-MobileNet-0.25 (BASELINE.json configs[1]): MobileNetV1 x0.25 backbone (first 3x3/2 conv, 13
+// depthwise-separable blocks), 64-channel FPN, SSH (32 | 16 | 16) and the same fused heads / anchor contract.
+// Activation tensors are zero-padded to 64 channels on the device so that every pointwise / FPN / SSH / head
+// conv runs on the MFMA implicit-GEMM kernel; depthwise 3x3 and the first conv have their own small kernels.
+void Graph::build_mnet025()
+{
+    const int H = net_h, W = net_w;
+    input = add_tensor(4, H, W);
+    auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
+    auto simple_op = [&](int kind, int layer, int in, int out) {
+        Op o{kind, layer, in, out, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 1, 0, 0, 0, 0};
+        ops.push_back(o);
+    };
+    int h = H / 2, w = W / 2;
+    int x = add_tensor(8, h, w);
+    simple_op(OP_FIRST, add_layer("conv1", 3, 8, 3, 2, 1, 1.0f / 128.0f, 0, 0, -1, 0, LK_FIRST3X3, 8), input, x);
+    static const int couts[13] = {16, 32, 32, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256};
+    static const int strides[13] = {1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1};
+    int cin = 8, c1 = -1, c2 = -1, c3 = -1;
+    for (int i = 0; i < 13; ++i) {
+        char nm[64];
+        const int ho = h / strides[i], wo = w / strides[i];
+        snprintf(nm, sizeof nm, "block%d_dw", i + 1);
+        const int tdw = add_tensor(cin, ho, wo);
+        simple_op(OP_DW, add_layer(nm, 1, cin, 3, strides[i], 1, 1.0f, 0, 0, -1, 0, LK_DEPTHWISE, T(tdw).C), x, tdw);
+        snprintf(nm, sizeof nm, "block%d_pw", i + 1);
+        const int tpw = add_tensor(couts[i], ho, wo);
+        add_conv(add_layer(nm, cin, couts[i], 1, 1, 0, 1.0f, 0, 0, -1, 0, LK_CONV, T(tpw).C), tdw, tpw, 1);
+        x = tpw; cin = couts[i]; h = ho; w = wo;
+        if (i == 4) c1 = x;   // 64 ch @ /8
+        if (i == 10) c2 = x;  // 128 ch @ /16
+        if (i == 12) c3 = x;  // 256 ch @ /32
+    }
+    // FPN, 64 channels
+    const int p3 = add_tensor(64, T(c3).H, T(c3).W);
+    add_conv(add_layer("fpn_lat3", 256, 64, 1, 1, 0, 1.0f, 0), c3, p3, 1);
+    const int p2pre = add_tensor(64, T(c2).H, T(c2).W);
+    { const int o = add_conv(add_layer("fpn_lat2", 128, 64, 1, 1, 0, 1.0f, 0), c2, p2pre, 1, p3); ops[o].res_up2 = 1; ops[o].res_post = 1; }
+    const int p2 = add_tensor(64, T(c2).H, T(c2).W);
+    add_conv(add_layer("fpn_aggr2", 64, 64, 3, 1, 1, 0.8f, 0), p2pre, p2, 1);
+    const int p1pre = add_tensor(64, T(c1).H, T(c1).W);
+    { const int o = add_conv(add_layer("fpn_lat1", 64, 64, 1, 1, 0, 1.0f, 0), c1, p1pre, 1, p2); ops[o].res_up2 = 1; ops[o].res_post = 1; }
+    const int p1 = add_tensor(64, T(c1).H, T(c1).W);
+    add_conv(add_layer("fpn_aggr1", 64, 64, 3, 1, 1, 0.8f, 0), p1pre, p1, 1);
+    // SSH: O[64] = [conv1 0:32 | ctx2 32:48 | ctx3b 48:64], ctx1: 64 -> 16, ctx3a: 16 -> 16; ReLU after concat
+    const int feats[3] = {p3, p2, p1};
+    for (int l = 0; l < 3; ++l) {
+        const int f = feats[l], fh = T(f).H, fw = T(f).W, st = kStrides[l];
+        char nm[64];
+        const int o = add_tensor(64, fh, fw);
+        snprintf(nm, sizeof nm, "ssh%d_conv1", st);
+        add_conv(add_layer(nm, 64, 32, 3, 1, 1, 1.0f, 0), f, o, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx1", st);
+        const int tc = add_tensor(16, fh, fw);
+        add_conv(add_layer(nm, 64, 16, 3, 1, 1, 1.0f, 0, 0, -1, 0, LK_CONV, 64), f, tc, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx2", st);
+        { Op &B = ops[add_conv(add_layer(nm, 16, 16, 3, 1, 1, 1.0f, 0, 0, -1, 0, LK_CONV, 32), tc, o, 1)]; B.y_coff = 32; B.n_valid = 16; }
+        snprintf(nm, sizeof nm, "ssh%d_ctx3a", st);
+        const int td = add_tensor(16, fh, fw);
+        add_conv(add_layer(nm, 16, 16, 3, 1, 1, 1.0f, 0, 0, -1, 0, LK_CONV, 64), tc, td, 1);
+        snprintf(nm, sizeof nm, "ssh%d_ctx3b", st);
+        { Op &C = ops[add_conv(add_layer(nm, 16, 16, 3, 1, 1, 1.0f, 0, 0, -1, 0, LK_CONV, 32), td, o, 1)]; C.y_coff = 48; C.n_valid = 16; }
+        snprintf(nm, sizeof nm, "head%d", st);
+        heads[l] = add_tensor(32, fh, fw, 1);
+        ops[add_conv(add_layer(nm, 64, 32, 1, 1, 0, 1.0f, 0), o, -1, 0, -1, -1, heads[l])].head_softmax = 1;
+    }
+}
+
 void Graph::plan()
 {
     const int nops = (int)ops.size();
@@ -240,6 +314,8 @@ int Graph::build(int backbone_, int w, int h)
     }
     if (backbone == RFD_BACKBONE_R50) {
         build_r50();
+    } else if (backbone == RFD_BACKBONE_MNET025) {
+        build_mnet025();
     } else {
         set_error("backbone %d is not implemented in this build", backbone);
         return RFD_ERR_INVALID_ARG;
@@ -254,6 +330,7 @@ double Graph::layer_macs(int i) const
     if (o.kind == OP_POOL) return 0.0;
     const Layer &L = layers[o.layer];
     if (o.kind == OP_STEM) return (double)(net_h / 2) * (net_w / 2) * L.cout * L.kh * L.kw * L.cin;
+    if (o.kind == OP_DW) return (double)tensors[o.out].H * tensors[o.out].W * L.cout * 9;
     const int t = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
     double m = (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
     if (o.layer2 >= 0) m += (double)tensors[t].H * tensors[t].W * L.cout * layers[o.layer2].cin;
@@ -277,11 +354,16 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     max_batch = max_batch_;
     RFD_HIP(hipMalloc((void **)&d_w, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMalloc((void **)&d_b, (g.b_total + g.a_total) * sizeof(float))); // biases, then affines
+    RFD_HIP(hipMemset(d_w, 0, g.w_total * sizeof(bf16_t)));
+    RFD_HIP(hipMemset(d_b, 0, (g.b_total + g.a_total) * sizeof(float)));
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
     for (size_t i = 0; i < d_buffers.size(); ++i)
+    {
         RFD_HIP(hipMalloc(&d_buffers[i], g.buffer_bytes_per_image[i] * (size_t)max_batch));
+        RFD_HIP(hipMemset(d_buffers[i], 0, g.buffer_bytes_per_image[i] * (size_t)max_batch));
+    }
     return RFD_OK;
 }
 
@@ -326,7 +408,7 @@ int Network::init_synthetic(uint64_t seed, hipStream_t s)
         const Layer &L = g.layers[li];
         const size_t n = (size_t)L.cout * L.kh * L.kw * L.cin;
         std::vector<float> w(n + 1), b(L.cout), sc(L.cout), sh(L.cout);
-        const float stdv = sqrtf(2.0f / (float)(L.kh * L.kw * L.cin)) * L.gain;
+        const float stdv = sqrtf(2.0f / (float)(L.kh * L.kw * L.cin)) * L.gain; // depthwise: cin = 1 -> fan-in 9
         Gauss gw{splitmix64(seed * 1315423911ull + li * 2654435761ull)};
         for (size_t i = 0; i < n; i += 2) {
             float a, c;
@@ -372,21 +454,45 @@ int Network::set_layer(int idx, const float *w, const float *bias, hipStream_t s
 {
     if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
-    const size_t K = (L.kh == 7 && L.cin == 3) ? 7 * 32 : (size_t)L.kh * L.kw * L.cin;
-    std::vector<bf16_t> hw((size_t)L.cout * K, 0);
-    if (L.kh == 7 && L.cin == 3) { // [64][7][7][3] -> [64][7][8 kx][4 c], zero padded
+    const int taps = L.kh * L.kw;
+    // logical [cout][kh][kw][cin] f32 -> device bf16, zero padded to the device shape
+    size_t rows = L.cout_d, K = 0;
+    std::vector<bf16_t> hw;
+    if (L.kind == LK_CONV0) { // [64][7][7][3] -> [64][7][8 kx][4 c]
+        K = 7 * 32; rows = L.cout;
+        hw.assign(rows * K, 0);
         for (int n = 0; n < L.cout; ++n)
             for (int ky = 0; ky < 7; ++ky)
                 for (int kx = 0; kx < 7; ++kx)
                     for (int c = 0; c < 3; ++c)
                         hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c] = f32_to_bf16_host(w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c]);
+    } else if (L.kind == LK_FIRST3X3) { // [8][3][3][3] -> [8][3][3][4]
+        K = 36; rows = L.cout;
+        hw.assign(rows * K, 0);
+        for (int n = 0; n < L.cout; ++n)
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < 3; ++c) hw[(size_t)n * 36 + t * 4 + c] = f32_to_bf16_host(w[((size_t)n * 9 + t) * 3 + c]);
+    } else if (L.kind == LK_DEPTHWISE) { // [C][3][3][1] -> [9][C_d]
+        K = L.cout_d; rows = 9;
+        hw.assign(rows * K, 0);
+        for (int c = 0; c < L.cout; ++c)
+            for (int t = 0; t < 9; ++t) hw[(size_t)t * K + c] = f32_to_bf16_host(w[(size_t)c * 9 + t]);
     } else {
-        for (size_t i = 0; i < hw.size(); ++i) hw[i] = f32_to_bf16_host(w[i]);
+        K = (size_t)taps * L.cin_d;
+        hw.assign(rows * K, 0);
+        for (int n = 0; n < L.cout; ++n)
+            for (int t = 0; t < taps; ++t)
+                for (int c = 0; c < L.cin; ++c)
+                    hw[(size_t)n * K + (size_t)t * L.cin_d + c] = f32_to_bf16_host(w[((size_t)n * taps + t) * L.cin + c]);
     }
-    RFD_HIP(hipMemcpy2DAsync(d_w + L.w_off, L.ldw * sizeof(bf16_t), hw.data(), K * sizeof(bf16_t), K * sizeof(bf16_t),
-                             L.cout, hipMemcpyHostToDevice, s));
-    if (bias) RFD_HIP(hipMemcpyAsync(d_b + L.b_off, bias, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
-    RFD_HIP(hipStreamSynchronize(s)); // hw goes out of scope
+    RFD_HIP(hipMemcpy2DAsync(d_w + L.w_off, L.ldw * sizeof(bf16_t), hw.data(), K * sizeof(bf16_t), K * sizeof(bf16_t), rows,
+                             hipMemcpyHostToDevice, s));
+    std::vector<float> hb(L.cout_d, 0.f);
+    if (bias) {
+        memcpy(hb.data(), bias, L.cout * sizeof(float));
+        RFD_HIP(hipMemcpyAsync(d_b + L.b_off, hb.data(), L.cout_d * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    RFD_HIP(hipStreamSynchronize(s)); // hw / hb go out of scope
     return RFD_OK;
 }
 
@@ -394,20 +500,34 @@ int Network::get_layer(int idx, float *w, float *bias, hipStream_t s)
 {
     if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
+    const int taps = L.kh * L.kw;
     if (w) {
-        const size_t K = (L.kh == 7 && L.cin == 3) ? 7 * 32 : (size_t)L.kh * L.kw * L.cin;
-        std::vector<bf16_t> hw((size_t)L.cout * K);
-        RFD_HIP(hipMemcpy2DAsync(hw.data(), K * sizeof(bf16_t), d_w + L.w_off, L.ldw * sizeof(bf16_t), K * sizeof(bf16_t),
-                                 L.cout, hipMemcpyDeviceToHost, s));
+        size_t rows = L.cout_d, K = (size_t)taps * L.cin_d;
+        if (L.kind == LK_CONV0) { rows = L.cout; K = 7 * 32; }
+        else if (L.kind == LK_FIRST3X3) { rows = L.cout; K = 36; }
+        else if (L.kind == LK_DEPTHWISE) { rows = 9; K = L.cout_d; }
+        std::vector<bf16_t> hw(rows * K);
+        RFD_HIP(hipMemcpy2DAsync(hw.data(), K * sizeof(bf16_t), d_w + L.w_off, L.ldw * sizeof(bf16_t), K * sizeof(bf16_t), rows,
+                                 hipMemcpyDeviceToHost, s));
         RFD_HIP(hipStreamSynchronize(s));
-        if (L.kh == 7 && L.cin == 3) {
+        if (L.kind == LK_CONV0) {
             for (int n = 0; n < L.cout; ++n)
                 for (int ky = 0; ky < 7; ++ky)
                     for (int kx = 0; kx < 7; ++kx)
                         for (int c = 0; c < 3; ++c)
                             w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c] = bf16_to_f32_host(hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c]);
+        } else if (L.kind == LK_FIRST3X3) {
+            for (int n = 0; n < L.cout; ++n)
+                for (int t = 0; t < 9; ++t)
+                    for (int c = 0; c < 3; ++c) w[((size_t)n * 9 + t) * 3 + c] = bf16_to_f32_host(hw[(size_t)n * 36 + t * 4 + c]);
+        } else if (L.kind == LK_DEPTHWISE) {
+            for (int c = 0; c < L.cout; ++c)
+                for (int t = 0; t < 9; ++t) w[(size_t)c * 9 + t] = bf16_to_f32_host(hw[(size_t)t * K + c]);
         } else {
-            for (size_t i = 0; i < hw.size(); ++i) w[i] = bf16_to_f32_host(hw[i]);
+            for (int n = 0; n < L.cout; ++n)
+                for (int t = 0; t < taps; ++t)
+                    for (int c = 0; c < L.cin; ++c)
+                        w[((size_t)n * taps + t) * L.cin + c] = bf16_to_f32_host(hw[(size_t)n * K + (size_t)t * L.cin_d + c]);
         }
     }
     if (bias) {
@@ -422,7 +542,7 @@ int Network::set_affine(int idx, const float *scale, const float *shift, hipStre
     if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
     RFD_HIP(hipMemcpyAsync(d_b + g.b_total + L.a_off, scale, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
-    RFD_HIP(hipMemcpyAsync(d_b + g.b_total + L.a_off + L.cout, shift, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
+    RFD_HIP(hipMemcpyAsync(d_b + g.b_total + L.a_off + L.cout_d, shift, L.cout * sizeof(float), hipMemcpyHostToDevice, s));
     RFD_HIP(hipStreamSynchronize(s));
     return RFD_OK;
 }
@@ -432,7 +552,7 @@ int Network::get_affine(int idx, float *scale, float *shift, hipStream_t s)
     if (idx < 0 || idx >= (int)g.layers.size() || !g.layers[idx].has_affine) { set_error("layer %d has no affine", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
     RFD_HIP(hipMemcpyAsync(scale, d_b + g.b_total + L.a_off, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
-    RFD_HIP(hipMemcpyAsync(shift, d_b + g.b_total + L.a_off + L.cout, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
+    RFD_HIP(hipMemcpyAsync(shift, d_b + g.b_total + L.a_off + L.cout_d, L.cout * sizeof(float), hipMemcpyDeviceToHost, s));
     RFD_HIP(hipStreamSynchronize(s));
     return RFD_OK;
 }
@@ -456,12 +576,18 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         if (o.kind == OP_CONV0) {
             RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off,
                                  (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+        } else if (o.kind == OP_FIRST) {
+            RFD_TRY(launch_first3x3((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out), B,
+                                    tin.H, tin.W, g.tensors[o.out].C, s));
+        } else if (o.kind == OP_DW) {
+            RFD_TRY(launch_dwconv3x3((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out), B,
+                                     tin.H, tin.W, tin.C, L.stride, s));
         } else if (o.kind == OP_STEM) {
             RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
-                                d_b + g.b_total + L.a_off + L.cout, (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+                                d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
         } else if (o.kind == OP_POOL) {
             RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
-                                        d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout, B, tin.H, tin.W,
+                                        d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout_d, B, tin.H, tin.W,
                                         tin.C, s));
         } else {
             const int tout = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
@@ -478,20 +604,21 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
                 const TensorDesc &t2 = g.tensors[o.in2];
                 p.x2 = (const bf16_t *)tensor_ptr(o.in2);
                 p.bias2 = d_b + L2.b_off;
-                p.H2 = t2.H; p.W2 = t2.W; p.Cin2 = L2.cin; p.stride2 = L2.stride;
+                p.H2 = t2.H; p.W2 = t2.W; p.Cin2 = L2.cin_d; p.stride2 = L2.stride;
             }
             if (o.in_affine >= 0) {
                 const Layer &La = g.layers[o.in_affine];
                 p.in_scale = d_b + g.b_total + La.a_off;
-                p.in_shift = d_b + g.b_total + La.a_off + La.cout;
+                p.in_shift = d_b + g.b_total + La.a_off + La.cout_d;
             }
             p.scale2 = d_b + g.b_total + L.a_off;
-            p.shift2 = d_b + g.b_total + L.a_off + L.cout;
+            p.shift2 = d_b + g.b_total + L.a_off + L.cout_d;
             p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out) : nullptr;
             p.y2 = o.out2 >= 0 ? (bf16_t *)tensor_ptr(o.out2) : nullptr;
             p.yf = o.outf >= 0 ? (float *)tensor_ptr(o.outf) : nullptr;
-            p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin;
-            p.Cout = L.cout + (o.layer_n2 >= 0 ? g.layers[o.layer_n2].cout : 0); // N-fused sibling: its rows follow
+            p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin_d;
+            p.Cout = L.cout_d + (o.layer_n2 >= 0 ? g.layers[o.layer_n2].cout_d : 0); // N-fused sibling: its rows follow
+            p.n_valid = o.n_valid;
             p.ldx = tin.C; p.x_coff = o.x_coff; p.y_split = o.y_split; p.y_split_add = o.y_split_add;
             p.KH = L.kh; p.KW = L.kw; p.stride = L.stride; p.pad = L.pad;
             p.Ho = g.tensors[tout].H; p.Wo = g.tensors[tout].W;

@@ -63,7 +63,7 @@ class rfd_stats(C.Structure):
 class rfd_layer_desc(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int),
                 ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("has_affine", C.c_int),
-                ("reserved", C.c_int * 4)]
+                ("kind", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class rfd_op_desc(C.Structure):
@@ -72,13 +72,13 @@ class rfd_op_desc(C.Structure):
                 ("res_up2", C.c_int), ("res_post", C.c_int), ("head_softmax", C.c_int),
                 ("y_coff", C.c_int), ("macs", C.c_double), ("in2", C.c_int), ("layer2", C.c_int),
                 ("in_affine", C.c_int), ("layer_n2", C.c_int), ("x_coff", C.c_int), ("y_split", C.c_int),
-                ("y_split_add", C.c_int), ("reserved", C.c_int * 1)]
+                ("y_split_add", C.c_int), ("n_valid", C.c_int)]
 
 
 class rfd_tensor_desc(C.Structure):
     _fields_ = [("channels", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("is_f32", C.c_int), ("buffer", C.c_int), ("is_input", C.c_int),
-                ("head_level", C.c_int), ("reserved", C.c_int * 4)]
+                ("head_level", C.c_int), ("channels_logical", C.c_int), ("reserved", C.c_int * 3)]
 
 
 # every symbol include/rfd.h declares (tests check that the library exports them all)
@@ -253,7 +253,7 @@ class RetinaFaceDetection:
         _check(self._L.rfd_init_synthetic_weights(self._ctx, seed))
 
     def get_layer(self, idx, desc):
-        w = np.zeros((desc.cout, desc.kh, desc.kw, desc.cin), np.float32)
+        w = np.zeros((desc.cout, desc.kh, desc.kw, desc.cin), np.float32)  # depthwise: cin = 1
         b = np.zeros(desc.cout, np.float32)
         _check(self._L.rfd_get_layer_weights(self._ctx, idx, w.ctypes.data, b.ctypes.data))
         return w, b

@@ -68,6 +68,15 @@ def test_graph_plan_has_no_aliasing(rfd):
         assert not set(ob) & {g.tensors[t].buffer for t in ins}
 
 
+def test_mobilenet_graph(rfd):
+    g = rfd.Graph(rfd.BACKBONE_MNET025, 640, 640)           # BASELINE.json configs[1]
+    assert sum(1 for l in g.layers if l.kind == 1) == 13    # depthwise 3x3 layers
+    assert abs(g.macs - 0.9811456e9) < 1e3
+    hl = {t.head_level: (t.height, t.width, t.channels) for t in g.tensors if t.head_level}
+    assert hl == {1: (20, 20, 32), 2: (40, 40, 32), 3: (80, 80, 32)}   # same head / anchor contract as R50
+    assert all(t.channels % 64 == 0 or t.is_f32 or t.is_input for t in g.tensors)
+
+
 def test_bad_graph_arguments(rfd):
     with pytest.raises(rfd.RfdError) as e:
         rfd.Graph(rfd.BACKBONE_R50, 641, 640)

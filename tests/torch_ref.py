@@ -41,6 +41,13 @@ class TorchRef:
             v = F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
             tensors[o.out] = bf16r(F.relu(v))
             return
+        if o.kind == 5:  # first 3x3/2 conv on R,G,B + bias + relu (MobileNet)
+            tensors[o.out] = bf16r(F.relu(F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=1)))
+            return
+        if o.kind == 4:  # depthwise 3x3 + bias + relu
+            tensors[o.out] = bf16r(F.relu(F.conv2d(x, self.w[o.layer], self.b[o.layer], stride=L.stride, padding=1,
+                                                   groups=L.cout)))
+            return
         if o.kind == 3:  # fused stem: conv0 + bias + relu (bf16) -> maxpool 3x3/2 pad 1 -> affine + relu
             v = bf16r(F.relu(F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)))
             s, t = self.aff[o.layer]
@@ -76,9 +83,9 @@ class TorchRef:
             y = bf16r(y)
             td = g.tensors[o.out]
             nout = y.shape[1]
-            if td.channels != nout:  # SSH concat buffer: channel n -> y_coff + n (+ y_split_add if n >= y_split)
+            if td.channels_logical != nout:  # SSH concat buffer: channel n -> y_coff + n (+ y_split_add if n >= y_split)
                 if o.out not in tensors:
-                    tensors[o.out] = torch.zeros(x.shape[0], td.channels, td.height, td.width)
+                    tensors[o.out] = torch.zeros(x.shape[0], td.channels_logical, td.height, td.width)
                 s = min(o.y_split, nout)
                 tensors[o.out][:, o.y_coff:o.y_coff + s] = y[:, :s]
                 if s < nout:
@@ -113,15 +120,26 @@ class TorchRef:
         return out
 
 
-def nchw_to_dev(t, is_f32=False):
-    """NCHW f32 torch tensor -> device layout (NHWC; bf16 bits as uint16, or f32)."""
+def nchw_to_dev(t, is_f32=False, channels=None):
+    """NCHW f32 torch tensor -> device layout (NHWC; bf16 bits as uint16, or f32), channels zero-padded."""
+    if channels is not None and channels > t.shape[1]:
+        t = torch.cat([t, torch.zeros(t.shape[0], channels - t.shape[1], t.shape[2], t.shape[3])], 1)
     a = t.permute(0, 2, 3, 1).contiguous()
     if is_f32:
         return a.numpy().astype(np.float32)
     return a.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
 
 
-def dev_to_nchw(a, is_f32=False):
+def dev_to_nchw(a, is_f32=False, channels=None):
+    """Inverse of nchw_to_dev; `channels` = logical channel count (the zero padding is checked and dropped)."""
+    t = _dev_to_nchw(a, is_f32)
+    if channels is not None and channels < t.shape[1]:
+        assert float(t[:, channels:].abs().max()) == 0.0, "channel padding is not zero"
+        t = t[:, :channels].contiguous()
+    return t
+
+
+def _dev_to_nchw(a, is_f32=False):
     if is_f32:
         return torch.from_numpy(a.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
     t = torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).to(torch.float32)
