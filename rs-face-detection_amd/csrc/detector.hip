@@ -294,7 +294,7 @@ int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on
     pp.out_nhwc4 = (bf16_t *)c->net.tensor_ptr(c->net.g.input);
     RFD_TRY(launch_preprocess(pp, n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[2], c->stream));
-    RFD_TRY(c->net.run(n, c->stream));
+    RFD_TRY(c->net.run_graphed(n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[3], c->stream));
     DecodeParams dp;
     fill_decode_params(c, dp);
@@ -573,7 +573,7 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
 }
 int rfd_debug_set_conv_tile(rfd_ctx *c, int tile)
 {
-    RFD_CHECK_ARG(c && tile >= 0 && tile <= 2, "bad argument");
+    RFD_CHECK_ARG(c && tile >= 0 && tile <= 4, "bad argument");
     RFD_TRY(c->ensure_network());
     c->net.force_tile = tile;
     return RFD_OK;

@@ -376,7 +376,7 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     }
     const int M = p.B * p.Ho * p.Wo;
     const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
-    if (p.Cout % 128 == 0) {
+    if (p.Cout % 128 == 0 && p.force_tile != 4) {
         // The 8-wave 256x128 tile with a 3-slot ring (1 workgroup per CU) measured 5-13 % SLOWER than two
         // co-resident 128x128 workgroups on every layer of this network (profiles/): opt-in only.
         (void)M; (void)nk;
@@ -387,7 +387,10 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     }
     if (p.Cout % 192 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 192, 2, 2, 2>(p, s); // fused SSH pair
     // 128x64: the 2-slot ring keeps 3 workgroups per CU, which measured faster than a deeper ring at 2
-    if (p.Cout % 64 == 0) return launch_conv_cfg<128, 64, 4, 1, 2>(p, s);
+    if (p.Cout % 64 == 0) {
+        if (p.force_tile == 3) return launch_conv_cfg<256, 64, 4, 1, 2>(p, s); // 64x64 wave tiles, 2 workgroups / CU
+        return launch_conv_cfg<128, 64, 4, 1, 2>(p, s);
+    }
     return launch_conv_cfg<128, 32, 4, 1, 2>(p, s);
 }
 

@@ -86,6 +86,7 @@ struct Network {
     int force_tile = 0; // test hook: 0 heuristic, 1 = 128-row tiles only, 2 = 256x128 wherever Cout % 128 == 0
     std::vector<hipEvent_t> ev; // 2 per op when profiling
     std::vector<float> op_ms;   // last profiled run
+    int prof_first = 0, prof_last = -1; // op range of the last run
 
     int create(int backbone, int net_w, int net_h, int max_batch);
     void destroy();
@@ -96,6 +97,12 @@ struct Network {
     int set_affine(int idx, const float *scale, const float *shift, hipStream_t s);
     void *tensor_ptr(int t) const { return d_buffers[g.tensors[t].buffer]; }
     int run(int B, hipStream_t s, int first_op = 0, int last_op = -1);
+    // whole op list replayed from a hipGraph captured per batch size (removes ~5 us of launch gap per kernel;
+    // matters at batch 1, where the network is launch-bound); falls back to run() while profiling
+    int run_graphed(int B, hipStream_t s);
+    std::vector<hipGraphExec_t> graph_exec; // indexed by B
+    std::vector<char> warmed;               // eager run done for this B (one-time kernel attribute set-up)
+    bool use_graph = true;
     int collect_profile(); // after the stream has drained
 };
 

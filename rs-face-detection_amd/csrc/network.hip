@@ -376,6 +376,9 @@ void Network::destroy()
     for (void *p : d_buffers)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (hipGraphExec_t ge : graph_exec)
+        if (ge) (void)hipGraphExecDestroy(ge);
+    graph_exec.clear();
     d_w = nullptr; d_b = nullptr; d_buffers.clear(); ev.clear();
 }
 
@@ -568,6 +571,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         for (size_t i = old; i < ev.size(); ++i) RFD_HIP(hipEventCreate(&ev[i]));
     }
     if (last_op < 0 || last_op >= nops) last_op = nops - 1;
+    prof_first = std::max(first_op, 0); prof_last = last_op;
     for (int i = std::max(first_op, 0); i <= last_op; ++i) {
         const Op &o = g.ops[i];
         const Layer &L = g.layers[o.layer];
@@ -632,12 +636,45 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
     return RFD_OK;
 }
 
+int Network::run_graphed(int B, hipStream_t s)
+{
+    if (!use_graph || profiling || B < 1 || B > max_batch) return run(B, s);
+    if ((int)graph_exec.size() <= max_batch) { graph_exec.assign(max_batch + 1, nullptr); warmed.assign(max_batch + 1, 0); }
+    if (graph_exec[B]) {
+        RFD_HIP(hipGraphLaunch(graph_exec[B], s));
+        return RFD_OK;
+    }
+    if (!warmed[B]) { // first call for this batch size runs eagerly (hipFuncSetAttribute etc. are not capturable)
+        warmed[B] = 1;
+        return run(B, s);
+    }
+    hipGraph_t graph = nullptr;
+    RFD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int st = run(B, s);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (st != RFD_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        use_graph = false; // capture unsupported here: stay eager
+        return st != RFD_OK ? st : run(B, s);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        use_graph = false;
+        return run(B, s);
+    }
+    graph_exec[B] = exec;
+    RFD_HIP(hipGraphLaunch(exec, s));
+    return RFD_OK;
+}
+
 int Network::collect_profile()
 {
     const int nops = (int)g.ops.size();
     op_ms.assign(nops, 0.f);
     if (!profiling || (int)ev.size() < 2 * nops) return RFD_OK;
-    for (int i = 0; i < nops; ++i) RFD_HIP(hipEventElapsedTime(&op_ms[i], ev[2 * i], ev[2 * i + 1]));
+    for (int i = prof_first; i <= prof_last && i < nops; ++i) RFD_HIP(hipEventElapsedTime(&op_ms[i], ev[2 * i], ev[2 * i + 1]));
     return RFD_OK;
 }
 

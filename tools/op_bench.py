@@ -33,10 +33,12 @@ for t in range(g.num_tensors):  # random bf16 activations everywhere (never benc
 for op in [int(x) for x in a.ops.split(",")]:
     o = g.ops[op]
     L = g.layers[o.layer]
+    det.set_profiling(True)
     det.debug_run(a.batch, op, op)
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(a.reps):
         det.debug_run(a.batch, op, op)
-    dt = (time.perf_counter() - t0) / a.reps
+        ts.append(float(det.op_profile(g.num_ops)[op]) * 1e-3)
+    dt = float(np.median(ts))
     fl = 2.0 * o.macs * a.batch
-    print("op %d %s: %.1f us/launch (host-timed, incl. sync) %.1f TF" % (op, L.name.decode(), dt * 1e6, fl / dt / 1e12))
+    print("op %d %s: %.1f us/launch (HIP events, median) %.1f TF" % (op, L.name.decode(), dt * 1e6, fl / dt / 1e12))
