@@ -220,6 +220,27 @@ RFD_API int rfd_nms_sorted(rfd_ctx *ctx, int32_t *keep, int *num_out, const floa
 RFD_API void _nms(int32_t *keep, int *num_out, float *boxes, int boxes_num, int boxes_dim, float thresh,
           int device_id);
 
+/* ---- next stage: FaceSelection::call, face_selection.rs:72-189, as a device epilogue.
+ *      Defaults = FaceSelectionConfig::new (config.rs:107-117).  found[i]: 0 = no face selected (reference:
+ *      (None, None)), 1 = box only, 3 = box + key points.  Only the rows the detector returned (count <=
+ *      max_det) take part. ---- */
+typedef struct rfd_selection_config {
+    float margin_center_left_ratio;  /* 0.3 */
+    float margin_center_right_ratio; /* 0.3 */
+    float margin_edge_ratio;         /* 0.1 */
+    float minimum_face_ratio;        /* 0.0075 */
+} rfd_selection_config;
+RFD_API void rfd_selection_config_default(rfd_selection_config *cfg);
+/* Stage-level: selection on host detections as returned by rfd_detect_batch (dets->boxes/landmarks/count),
+ * img_h/img_w [n] = source frame sizes; out_box [n][5], out_kps [n][10], found [n].  Host pointers. */
+RFD_API int rfd_select_faces(rfd_ctx *ctx, const rfd_dets *dets, const int *img_h, const int *img_w, int n,
+                             const rfd_selection_config *cfg, int is_enroll, float *out_box, float *out_kps,
+                             int32_t *found);
+/* Fused: detect n frames (host buffers) and return only the selected face of each: detections stay in HBM,
+ * 16 floats per frame cross PCIe.  = FacePipeline::extract lines 198-208 (pipeline.rs). */
+RFD_API int rfd_detect_select_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, const rfd_selection_config *cfg,
+                                    int is_enroll, float *out_box, float *out_kps, int32_t *found);
+
 /* ---- introspection ---- */
 RFD_API int rfd_get_stats(rfd_ctx *ctx, rfd_stats *stats);
 RFD_API int rfd_get_config(const rfd_ctx *ctx, rfd_config *cfg);

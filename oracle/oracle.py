@@ -57,6 +57,9 @@ def lib():
         L.rfd_oracle_preprocess.argtypes = [_u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p]
         L.rfd_oracle_preprocess.restype = C.c_float
+        L.rfd_oracle_face_selection.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                C.c_float, C.c_float, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]
+        L.rfd_oracle_face_selection.restype = C.c_int
         _lib = L
     return _lib
 
@@ -169,3 +172,21 @@ def preprocess(src, size_w=640, size_h=640):
     sc = lib().rfd_oracle_preprocess(src, src.shape[0], src.shape[1], src.strides[0], size_w,
                                      size_h, det_img.ctypes.data, tensor.ctypes.data)
     return det_img, tensor, np.float32(sc)
+
+
+def face_selection(boxes, kps, img_h, img_w, is_enroll=False, margin_center_left_ratio=0.3,
+                   margin_center_right_ratio=0.3, margin_edge_ratio=0.1, minimum_face_ratio=0.0075):
+    """FaceSelection::call (face_selection.rs:72-189), defaults = FaceSelectionConfig::new (config.rs:107-117).
+    Returns (box [5] or None, kps [5,2] or None)."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 5)
+    k = np.ascontiguousarray(kps, np.float32).reshape(-1, 10)
+    ob = np.zeros(5, np.float32)
+    ok = np.zeros(10, np.float32)
+    found = C.c_int(0)
+    r = lib().rfd_oracle_face_selection(b if len(b) else np.zeros((1, 5), np.float32),
+                                        k if len(k) else np.zeros((1, 10), np.float32), b.shape[0], img_h, img_w,
+                                        margin_center_left_ratio, margin_center_right_ratio, margin_edge_ratio,
+                                        minimum_face_ratio, 1 if is_enroll else 0, ob, ok, C.byref(found))
+    if not r:
+        return None, None
+    return ob, (ok.reshape(5, 2) if found.value else None)

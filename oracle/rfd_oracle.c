@@ -456,3 +456,89 @@ RFD_API float rfd_oracle_preprocess(const uint8_t *src, int img_h, int img_w, pt
     if (!det_img) free(canvas);
     return det_scale;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * FaceSelection::call, src/pipeline/module/face_selection.rs:72-189, with
+ * get_biggest_area_face :28-53.  boxes [k][5], kps [k][5][2] (the detector's outputs), image size of
+ * the SOURCE frame.  Returns 1 and fills out_box[5] / out_kps[10] (kps_found = 0 when no key points
+ * were matched, :153-176) or 0 when nothing was selected.  The reference's quirks are kept on purpose:
+ * "area" is (x_max - x_min)^2 (:113), strict `>` keeps the FIRST maximum, and the key points are those of
+ * the first detection within 2 px of the chosen box (:163-173), not necessarily the chosen row.
+ * ------------------------------------------------------------------------------------------ */
+RFD_API int rfd_oracle_face_selection(const float *boxes, const float *kps, int k, int img_h, int img_w,
+                                      float margin_center_left_ratio, float margin_center_right_ratio,
+                                      float margin_edge_ratio, float minimum_face_ratio, int is_enroll,
+                                      float *out_box, float *out_kps, int *kps_found)
+{
+    *kps_found = 0;
+    if (is_enroll) { /* :84-105: biggest (xmax-xmin)*(ymax-ymin), strict >, from 0.0 */
+        float biggest = 0.0f;
+        int sel = -1;
+        for (int i = 0; i < k; ++i) {
+            const float *b = boxes + 5 * i;
+            if ((b[2] - b[0]) * (b[3] - b[1]) > biggest) {
+                biggest = (b[2] - b[0]) * (b[3] - b[1]);
+                sel = i;
+            }
+        }
+        if (sel < 0) return 0;
+        memcpy(out_box, boxes + 5 * sel, 5 * sizeof(float));
+        memcpy(out_kps, kps + 10 * sel, 10 * sizeof(float));
+        *kps_found = 1;
+        return 1;
+    }
+    const float W = (float)img_w, H = (float)img_h;
+    const float margin_center_left = margin_center_left_ratio * W;   /* :107 */
+    const float margin_center_right = margin_center_right_ratio * W; /* :108 */
+    float margin_edge = margin_edge_ratio * W;                        /* :109 */
+    margin_edge = fminf(50.0f, margin_edge);                          /* :110 */
+    const float x_cen = W / 2.0f;                                     /* :112 */
+    unsigned char *valid = (unsigned char *)calloc((size_t)(k > 0 ? k : 1), 1);
+    unsigned char *center = (unsigned char *)calloc((size_t)(k > 0 ? k : 1), 1);
+    int n_valid = 0, n_center = 0;
+    for (int i = 0; i < k; ++i) { /* :114-131 */
+        const float *d = boxes + 5 * i;
+        const float area = (d[2] - d[0]) * (d[2] - d[0]);
+        const float bcw = (d[0] + d[2]) / 2.0f, bch = (d[1] + d[3]) / 2.0f;
+        if (bcw >= margin_edge && bcw <= W - margin_edge && bch >= margin_edge && bch <= H - margin_edge &&
+            area / (H * W) >= minimum_face_ratio) {
+            valid[i] = 1;
+            ++n_valid;
+        }
+    }
+    for (int i = 0; i < k; ++i) { /* :133-139 */
+        if (!valid[i]) continue;
+        const float bcw = (boxes[5 * i] + boxes[5 * i + 2]) / 2.0f;
+        if (-margin_center_left <= bcw - x_cen && bcw - x_cen <= margin_center_right) {
+            center[i] = 1;
+            ++n_center;
+        }
+    }
+    const unsigned char *pool = center; /* :141-147 */
+    if (n_center == 0) pool = n_valid == 0 ? NULL : valid;
+    float max_size = 0.0f;
+    int sel = -1;
+    for (int i = 0; i < k; ++i) { /* :152-158 */
+        if (pool && !pool[i]) continue;
+        const float *r = boxes + 5 * i;
+        const float tem = (r[2] - r[0]) + (r[3] - r[1]);
+        if (tem > max_size) {
+            max_size = tem;
+            sel = i;
+        }
+    }
+    free(valid);
+    free(center);
+    if (sel < 0) return 0; /* :159-161 */
+    memcpy(out_box, boxes + 5 * sel, 5 * sizeof(float));
+    for (int i = 0; i < k; ++i) { /* :163-180 */
+        const float *b = boxes + 5 * i;
+        if (fabsf(out_box[0] - b[0]) <= 2.0f && fabsf(out_box[1] - b[1]) <= 2.0f && fabsf(out_box[2] - b[2]) <= 2.0f &&
+            fabsf(out_box[3] - b[3]) <= 2.0f) {
+            memcpy(out_kps, kps + 10 * i, 10 * sizeof(float));
+            *kps_found = 1;
+            break;
+        }
+    }
+    return 1;
+}

@@ -111,6 +111,7 @@ struct rfd_ctx {
     DevBuf staging, imgs, in4, rows, keys, sorted_keys, sorted_boxes, count, det_scale;
     DevBuf out_boxes, out_lmk, out_count, out_total, out_gidx;
     DevBuf scratch[12];
+    DevBuf sel_dims, sel_out;
     // pinned host ring for per-call descriptors, so enqueueing never blocks on the previous call
     static constexpr int kRing = 4;
     PreImage *pin_imgs[kRing] = {};
@@ -275,7 +276,7 @@ int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
     return RFD_OK;
 }
 
-int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on_device, int async)
+int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on_device, int async, bool frames_on_device)
 {
     RFD_CHECK_ARG(c != nullptr, "ctx is null");
     RFD_CHECK_ARG(out && out->boxes && out->landmarks && out->count, "output buffers are null");
@@ -285,7 +286,7 @@ int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     std::vector<float> scales;
     RFD_HIP(hipEventRecord(c->ev[0], c->stream));
-    RFD_TRY(stage_frames(c, imgs, n, on_device, scales));
+    RFD_TRY(stage_frames(c, imgs, n, frames_on_device, scales));
     RFD_HIP(hipEventRecord(c->ev[1], c->stream));
     PreParams pp;
     memset(&pp, 0, sizeof pp);
@@ -414,6 +415,7 @@ void rfd_destroy(rfd_ctx *c)
                       &c->out_gidx};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->scratch) b.release();
+    c->sel_dims.release(); c->sel_out.release();
     for (int i = 0; i < 10; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < rfd_ctx::kRing; ++i) {
@@ -632,12 +634,12 @@ int rfd_set_layer_affine(rfd_ctx *c, int idx, const float *scale, const float *s
 // ---- hot path ----
 int rfd_detect_batch(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
 {
-    return detect_impl(c, imgs, n, out, false, 0);
+    return detect_impl(c, imgs, n, out, false, 0, false);
 }
 int rfd_detect_batch_device(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, int async)
 {
     RFD_CHECK_ARG(out && out->total, "out->total must be a device buffer for the device entry point");
-    return detect_impl(c, imgs, n, out, true, async);
+    return detect_impl(c, imgs, n, out, true, async, true);
 }
 int rfd_sync(rfd_ctx *c)
 {
@@ -732,6 +734,74 @@ int rfd_decode_nms(rfd_ctx *c, const float *const heads[9], int n, const float *
     RFD_TRY(finish_stats(c, n, false, false));
     for (int i = 0; i < n; ++i) c->stats.detections += out->total ? out->total[i] : out->count[i];
     return RFD_OK;
+}
+
+void rfd_selection_config_default(rfd_selection_config *cfg)
+{
+    if (!cfg) return;
+    cfg->margin_center_left_ratio = 0.3f;  // config.rs:110
+    cfg->margin_center_right_ratio = 0.3f; // config.rs:111
+    cfg->margin_edge_ratio = 0.1f;         // config.rs:112
+    cfg->minimum_face_ratio = 0.0075f;     // config.rs:113
+}
+
+// selection over device-resident detection slabs; results copied to the host pointers
+static int select_impl(rfd_ctx *c, const float *d_boxes, const float *d_lmk, const int *d_count, const int *img_h,
+                       const int *img_w, int n, const rfd_selection_config *cfg, int is_enroll, float *out_box,
+                       float *out_kps, int32_t *found)
+{
+    rfd_selection_config def;
+    rfd_selection_config_default(&def);
+    if (!cfg) cfg = &def;
+    RFD_TRY(c->sel_dims.reserve((size_t)2 * n * sizeof(int)));
+    RFD_TRY(c->sel_out.reserve((size_t)n * 16 * sizeof(float)));
+    std::vector<int> dims(2 * n);
+    for (int i = 0; i < n; ++i) { dims[i] = img_h[i]; dims[n + i] = img_w[i]; }
+    RFD_HIP(hipMemcpyAsync(c->sel_dims.p, dims.data(), 2 * n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    SelectParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.boxes = d_boxes; sp.lmk = d_lmk; sp.count = d_count;
+    sp.img_h = (const int *)c->sel_dims.p; sp.img_w = sp.img_h + n;
+    sp.n = n; sp.max_det = c->cfg.max_det; sp.is_enroll = is_enroll;
+    sp.margin_center_left_ratio = cfg->margin_center_left_ratio;
+    sp.margin_center_right_ratio = cfg->margin_center_right_ratio;
+    sp.margin_edge_ratio = cfg->margin_edge_ratio;
+    sp.minimum_face_ratio = cfg->minimum_face_ratio;
+    float *o = (float *)c->sel_out.p;
+    sp.out_box = o; sp.out_kps = o + (size_t)n * 5; sp.out_found = (int *)(o + (size_t)n * 15);
+    RFD_TRY(launch_face_select(sp, c->stream));
+    RFD_HIP(hipMemcpyAsync(out_box, sp.out_box, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(out_kps, sp.out_kps, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(found, sp.out_found, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream)); // dims is a host temporary
+    return RFD_OK;
+}
+
+int rfd_select_faces(rfd_ctx *c, const rfd_dets *dets, const int *img_h, const int *img_w, int n,
+                     const rfd_selection_config *cfg, int is_enroll, float *out_box, float *out_kps, int32_t *found)
+{
+    RFD_CHECK_ARG(c && dets && dets->boxes && dets->landmarks && dets->count && img_h && img_w && out_box && out_kps && found,
+                  "null argument");
+    if (n < 1 || n > c->cfg.max_batch_size) { set_error("batch %d exceeds max_batch_size %d", n, c->cfg.max_batch_size); return RFD_ERR_CAPACITY; }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    const size_t MD = (size_t)c->cfg.max_det;
+    RFD_HIP(hipMemcpyAsync(c->out_boxes.p, dets->boxes, n * MD * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipMemcpyAsync(c->out_lmk.p, dets->landmarks, n * MD * 10 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipMemcpyAsync(c->out_count.p, dets->count, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    return select_impl(c, (const float *)c->out_boxes.p, (const float *)c->out_lmk.p, (const int *)c->out_count.p, img_h, img_w,
+                       n, cfg, is_enroll, out_box, out_kps, found);
+}
+
+int rfd_detect_select_batch(rfd_ctx *c, const rfd_image *imgs, int n, const rfd_selection_config *cfg, int is_enroll,
+                            float *out_box, float *out_kps, int32_t *found)
+{
+    RFD_CHECK_ARG(c && out_box && out_kps && found, "null argument");
+    RFD_TRY(check_images(c, imgs, n));
+    rfd_dets dev = {(float *)c->out_boxes.p, (float *)c->out_lmk.p, (int32_t *)c->out_count.p, (int32_t *)c->out_total.p};
+    RFD_TRY(detect_impl(c, imgs, n, &dev, /*outputs stay on the device*/ true, /*async*/ 1, /*frames on host*/ false));
+    std::vector<int> hh(n), ww(n);
+    for (int i = 0; i < n; ++i) { hh[i] = imgs[i].height; ww[i] = imgs[i].width; }
+    return select_impl(c, dev.boxes, dev.landmarks, dev.count, hh.data(), ww.data(), n, cfg, is_enroll, out_box, out_kps, found);
 }
 
 int rfd_nms_sorted(rfd_ctx *c, int32_t *keep, int *num_out, const float *boxes, int boxes_num, int boxes_dim,

@@ -65,6 +65,20 @@ struct NmsParams {
 };
 int launch_nms(NmsParams p, int n_images, hipStream_t s);
 
+// FaceSelection::call on the device (face_selection.rs:72-189): per image, over its kept detections
+struct SelectParams {
+    const float *boxes; // [n][max_det][5]
+    const float *lmk;   // [n][max_det][10]
+    const int *count;   // [n]
+    const int *img_h, *img_w; // [n] source frame sizes
+    int n, max_det, is_enroll;
+    float margin_center_left_ratio, margin_center_right_ratio, margin_edge_ratio, minimum_face_ratio;
+    float *out_box;     // [n][5]
+    float *out_kps;     // [n][10]
+    int *out_found;     // [n]: 0 nothing selected, 1 box only, 3 box + key points
+};
+int launch_face_select(const SelectParams &p, hipStream_t s);
+
 // ---------------------------------------------------------------- convolution engine (kernels_conv.hip)
 // Activations: NHWC bf16.  Weights: [Cout][KH][KW][Cin] bf16 (K contiguous).  f32 accumulate on MFMA.
 struct ConvParams {

@@ -390,6 +390,88 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FaceSelection::call (reference src/pipeline/module/face_selection.rs:72-189) as
+// an optional device epilogue: one thread per image walks that image's kept rows in the reference's loop
+// order (strict `>` keeps the first maximum; the key points are those of the first row within 2 px of
+// the chosen box), so the result is bit-identical to the CPU logic by construction and only 16 floats
+// per image have to leave the GPU.  Scalar work on <= max_det rows: latency-, not bandwidth-bound.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) face_select_kernel(SelectParams p)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= p.n) return;
+    const int k = p.count[b];
+    const float *boxes = p.boxes + (size_t)b * p.max_det * 5;
+    const float *kps = p.lmk + (size_t)b * p.max_det * 10;
+    float *ob = p.out_box + (size_t)b * 5, *ok = p.out_kps + (size_t)b * 10;
+    int sel = -1, kp_row = -1;
+    if (p.is_enroll) { // get_biggest_area_face :28-53
+        float biggest = 0.0f;
+        for (int i = 0; i < k; ++i) {
+            const float *r = boxes + 5 * i;
+            const float a = (r[2] - r[0]) * (r[3] - r[1]);
+            if (a > biggest) { biggest = a; sel = i; }
+        }
+        kp_row = sel;
+    } else {
+        const float W = (float)p.img_w[b], H = (float)p.img_h[b];
+        const float mcl = p.margin_center_left_ratio * W, mcr = p.margin_center_right_ratio * W; // :107-108
+        const float me = fminf(50.0f, p.margin_edge_ratio * W);                                   // :109-110
+        const float x_cen = W / 2.0f;
+        int n_valid = 0, n_center = 0;
+        for (int i = 0; i < k; ++i) { // :114-139
+            const float *d = boxes + 5 * i;
+            const float area = (d[2] - d[0]) * (d[2] - d[0]); // sic (:113)
+            const float bcw = (d[0] + d[2]) / 2.0f, bch = (d[1] + d[3]) / 2.0f;
+            const bool valid = bcw >= me && bcw <= W - me && bch >= me && bch <= H - me && area / (H * W) >= p.minimum_face_ratio;
+            n_valid += valid;
+            n_center += valid && (-mcl <= bcw - x_cen && bcw - x_cen <= mcr);
+        }
+        const int mode = n_center ? 2 : (n_valid ? 1 : 0); // pool: centre boxes, else valid boxes, else all (:141-147)
+        float max_size = 0.0f;
+        for (int i = 0; i < k; ++i) { // :152-158
+            const float *d = boxes + 5 * i;
+            if (mode) {
+                const float area = (d[2] - d[0]) * (d[2] - d[0]);
+                const float bcw = (d[0] + d[2]) / 2.0f, bch = (d[1] + d[3]) / 2.0f;
+                const bool valid = bcw >= me && bcw <= W - me && bch >= me && bch <= H - me && area / (H * W) >= p.minimum_face_ratio;
+                if (!valid) continue;
+                if (mode == 2 && !(-mcl <= bcw - x_cen && bcw - x_cen <= mcr)) continue;
+            }
+            const float tem = (d[2] - d[0]) + (d[3] - d[1]);
+            if (tem > max_size) { max_size = tem; sel = i; }
+        }
+        if (sel >= 0) { // :163-180
+            const float *o = boxes + 5 * sel;
+            for (int i = 0; i < k; ++i) {
+                const float *r = boxes + 5 * i;
+                if (fabsf(o[0] - r[0]) <= 2.0f && fabsf(o[1] - r[1]) <= 2.0f && fabsf(o[2] - r[2]) <= 2.0f && fabsf(o[3] - r[3]) <= 2.0f) {
+                    kp_row = i;
+                    break;
+                }
+            }
+        }
+    }
+    int found = 0;
+    if (sel >= 0) {
+        found = 1;
+        for (int c = 0; c < 5; ++c) ob[c] = boxes[5 * sel + c];
+        if (kp_row >= 0) {
+            found = 3;
+            for (int c = 0; c < 10; ++c) ok[c] = kps[10 * kp_row + c];
+        }
+    }
+    p.out_found[b] = found;
+}
+
+int launch_face_select(const SelectParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(face_select_kernel, dim3(ceil_div(p.n, 64)), dim3(64), 0, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
 size_t nms_lds_bytes(int total_anchors, bool reg)
 {
     const int nwords = ceil_div(total_anchors, 64);

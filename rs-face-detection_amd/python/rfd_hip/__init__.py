@@ -90,7 +90,8 @@ API_SYMBOLS = [
     "rfd_set_layer_weights", "rfd_get_layer_affine", "rfd_set_layer_affine", "rfd_detect_batch",
     "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
-    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile",
+    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_selection_config_default",
+    "rfd_select_faces", "rfd_detect_select_batch",
 ]
 
 _lib = None
@@ -149,6 +150,10 @@ def load_library(path=None):
     L.rfd_debug_tensor_io.argtypes = [vp, ci, ci, vp, ci]
     L.rfd_debug_run_ops.argtypes = [vp, ci, ci, ci]
     L.rfd_debug_set_conv_tile.argtypes = [vp, ci]
+    L.rfd_selection_config_default.argtypes = [vp]
+    L.rfd_selection_config_default.restype = None
+    L.rfd_select_faces.argtypes = [vp, C.POINTER(rfd_dets), vp, vp, ci, vp, ci, vp, vp, vp]
+    L.rfd_detect_select_batch.argtypes = [vp, C.POINTER(rfd_image), ci, vp, ci, vp, vp, vp]
     if path is None:
         _lib = L
     return L
@@ -332,6 +337,47 @@ class RetinaFaceDetection:
     def set_stream(self, hip_stream):
         """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None restores."""
         _check(self._L.rfd_set_stream(self._ctx, hip_stream))
+
+    # ---- next stage: FaceSelection::call (face_selection.rs:72-189) ----
+    @staticmethod
+    def _sel_cfg(cfg):
+        c = (C.c_float * 4)(0.3, 0.3, 0.1, 0.0075)  # FaceSelectionConfig::new, config.rs:107-117
+        if cfg is not None:
+            for i, v in enumerate(cfg):
+                c[i] = v
+        return c
+
+    @staticmethod
+    def _sel_out(box, kps, found):
+        return [(box[i].copy() if found[i] & 1 else None, kps[i].reshape(5, 2).copy() if found[i] == 3 else None)
+                for i in range(len(found))]
+
+    def select_faces(self, dets, sizes, is_enroll=False, cfg=None):
+        """dets: list of (det [K,5], kps [K,5,2]) per image; sizes: list of (h, w) of the source frames."""
+        n = len(dets)
+        d, boxes, lmk, count, total = self._alloc_dets(n)
+        for i, (a, b) in enumerate(dets):
+            k = min(len(a), self.max_det)
+            boxes[i, :k] = a[:k]
+            lmk[i, :k] = b[:k]
+            count[i] = k
+        hh = np.array([s[0] for s in sizes], np.int32)
+        ww = np.array([s[1] for s in sizes], np.int32)
+        ob, ok, fd = np.zeros((n, 5), np.float32), np.zeros((n, 10), np.float32), np.zeros(n, np.int32)
+        c = self._sel_cfg(cfg)
+        _check(self._L.rfd_select_faces(self._ctx, C.byref(d), hh.ctypes.data, ww.ctypes.data, n, C.addressof(c),
+                                        1 if is_enroll else 0, ob.ctypes.data, ok.ctypes.data, fd.ctypes.data))
+        return self._sel_out(ob, ok, fd)
+
+    def detect_select(self, frames, is_enroll=False, cfg=None):
+        """FacePipeline::extract lines 198-208: detect, then return only the selected face of each frame."""
+        arr, keep = self._images(frames)
+        n = len(frames)
+        ob, ok, fd = np.zeros((n, 5), np.float32), np.zeros((n, 10), np.float32), np.zeros(n, np.int32)
+        c = self._sel_cfg(cfg)
+        _check(self._L.rfd_detect_select_batch(self._ctx, arr, n, C.addressof(c), 1 if is_enroll else 0,
+                                               ob.ctypes.data, ok.ctypes.data, fd.ctypes.data))
+        return self._sel_out(ob, ok, fd)
 
     # ---- stage-level entry points ----
     def preprocess(self, frames):

@@ -171,3 +171,25 @@ def test_preprocess_layout(oracle):
     assert np.all(det_img[nh:] == 0)                                       # zero canvas below the paste
     assert np.array_equal(det_img[:nh, :nw], oracle.resize_linear(img, nh, nw))
     assert np.array_equal(tensor, det_img[..., ::-1].transpose(2, 0, 1).astype(np.float32))  # BGR->RGB planes
+
+
+def test_face_selection_semantics(oracle):
+    """FaceSelection::call (face_selection.rs:72-189) on hand-checked cases, image 720x1280."""
+    k = np.arange(40, dtype=np.float32).reshape(4, 5, 2)
+    b = np.array([[100, 100, 300, 350, .9],      # big but off-centre (centre x = 200 < 640 - 384)
+                  [400, 200, 520, 340, .8],      # centred
+                  [410, 210, 500, 300, .75],     # centred, smaller
+                  [10, 10, 30, 30, .7]], np.float32)
+    ob, ok = oracle.face_selection(b, k, 720, 1280)
+    assert ob.tolist() == b[1].tolist() and np.array_equal(ok, k[1])
+    ob, ok = oracle.face_selection(b, k, 720, 1280, is_enroll=True)   # enroll: biggest area wins
+    assert ob.tolist() == b[0].tolist() and np.array_equal(ok, k[0])
+    assert oracle.face_selection(b[:0], k[:0], 720, 1280) == (None, None)
+    # no valid box (all tiny): falls back to ALL boxes, largest w+h, first maximum on ties
+    t = np.array([[0, 0, 5, 5, .9], [600, 300, 605, 305, .8]], np.float32)
+    ob, ok = oracle.face_selection(t, k[:2], 720, 1280)
+    assert ob.tolist() == t[0].tolist()
+    # key points come from the FIRST row within 2 px of the chosen box (:163-173)
+    d = np.array([[401, 201, 521, 341, .9], [400, 200, 522, 342, .8]], np.float32)
+    ob, ok = oracle.face_selection(d, k[:2], 720, 1280)
+    assert ob.tolist() == d[1].tolist() and np.array_equal(ok, k[0])
