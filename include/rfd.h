@@ -169,6 +169,12 @@ RFD_API int rfd_num_layers(const rfd_ctx *ctx);
  * BatchNorm is expected to be folded into weights/bias by the caller. */
 RFD_API int rfd_get_layer_weights(rfd_ctx *ctx, int idx, float *weights, float *bias);
 RFD_API int rfd_set_layer_weights(rfd_ctx *ctx, int idx, const float *weights, const float *bias);
+/* Weight file (replaces Triton's model repository entry for the detector): little-endian; header "RFDW", u32
+ * version = 1, u32 backbone, u32 n_layers; per layer: char name[64], i32 cin, cout, kh, kw, stride, pad, kind,
+ * has_affine, then f32 weights [cout][kh][kw][cin], f32 bias [cout], and if has_affine f32 scale [cout], shift
+ * [cout].  BatchNorm must be folded by the exporter.  rfd_load_weights checks every shape against the graph. */
+RFD_API int rfd_save_weights(rfd_ctx *ctx, const char *path);
+RFD_API int rfd_load_weights(rfd_ctx *ctx, const char *path);
 /* the post-add affine (scale, shift per output channel) of layers with has_affine */
 RFD_API int rfd_get_layer_affine(rfd_ctx *ctx, int idx, float *scale, float *shift);
 RFD_API int rfd_set_layer_affine(rfd_ctx *ctx, int idx, const float *scale, const float *shift);

@@ -631,6 +631,88 @@ int rfd_set_layer_affine(rfd_ctx *c, int idx, const float *scale, const float *s
     return c->net.set_affine(idx, scale, shift, c->stream);
 }
 
+namespace {
+struct LayerRecord { char name[64]; int32_t cin, cout, kh, kw, stride, pad, kind, has_affine; };
+}
+
+int rfd_save_weights(rfd_ctx *c, const char *path)
+{
+    RFD_CHECK_ARG(c && path, "null argument");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    if (!c->net.weights_ready) { set_error("network weights are not initialised"); return RFD_ERR_STATE; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("cannot open %s for writing", path); return RFD_ERR_IO; }
+    const uint32_t hdr[3] = {1u, (uint32_t)c->cfg.backbone, (uint32_t)c->net.g.layers.size()};
+    bool ok = fwrite("RFDW", 1, 4, f) == 4 && fwrite(hdr, 4, 3, f) == 3;
+    for (size_t i = 0; ok && i < c->net.g.layers.size(); ++i) {
+        const Layer &L = c->net.g.layers[i];
+        LayerRecord rec;
+        memset(&rec, 0, sizeof rec);
+        snprintf(rec.name, sizeof rec.name, "%s", L.name.c_str());
+        rec.cin = L.cin; rec.cout = L.cout; rec.kh = L.kh; rec.kw = L.kw; rec.stride = L.stride; rec.pad = L.pad;
+        rec.kind = L.kind; rec.has_affine = L.has_affine;
+        const size_t nw = (size_t)L.cout * L.kh * L.kw * L.cin;
+        std::vector<float> w(nw), b(L.cout), sc(L.cout), sh(L.cout);
+        const int st = c->net.get_layer((int)i, w.data(), b.data(), c->stream);
+        if (st != RFD_OK) { fclose(f); return st; }
+        ok = fwrite(&rec, sizeof rec, 1, f) == 1 && fwrite(w.data(), 4, nw, f) == nw && fwrite(b.data(), 4, L.cout, f) == (size_t)L.cout;
+        if (ok && L.has_affine) {
+            const int sa = c->net.get_affine((int)i, sc.data(), sh.data(), c->stream);
+            if (sa != RFD_OK) { fclose(f); return sa; }
+            ok = fwrite(sc.data(), 4, L.cout, f) == (size_t)L.cout && fwrite(sh.data(), 4, L.cout, f) == (size_t)L.cout;
+        }
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("short write to %s", path); return RFD_ERR_IO; }
+    return RFD_OK;
+}
+
+int rfd_load_weights(rfd_ctx *c, const char *path)
+{
+    RFD_CHECK_ARG(c && path, "null argument");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return RFD_ERR_IO; }
+    char magic[4];
+    uint32_t hdr[3];
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "RFDW", 4) != 0 || fread(hdr, 4, 3, f) != 3 || hdr[0] != 1u) {
+        fclose(f);
+        set_error("%s is not an RFDW version-1 weight file", path);
+        return RFD_ERR_IO;
+    }
+    if (hdr[1] != (uint32_t)c->cfg.backbone || hdr[2] != (uint32_t)c->net.g.layers.size()) {
+        fclose(f);
+        set_error("%s holds backbone %u with %u layers; the context expects backbone %d with %zu layers", path, hdr[1], hdr[2],
+                  c->cfg.backbone, c->net.g.layers.size());
+        return RFD_ERR_INVALID_ARG;
+    }
+    for (size_t i = 0; i < c->net.g.layers.size(); ++i) {
+        const Layer &L = c->net.g.layers[i];
+        LayerRecord rec;
+        if (fread(&rec, sizeof rec, 1, f) != 1) { fclose(f); set_error("%s is truncated (layer %zu)", path, i); return RFD_ERR_IO; }
+        rec.name[63] = 0;
+        if (rec.cin != L.cin || rec.cout != L.cout || rec.kh != L.kh || rec.kw != L.kw || rec.stride != L.stride ||
+            rec.kind != L.kind || rec.has_affine != L.has_affine) {
+            fclose(f);
+            set_error("%s: layer %zu (%s) does not match the graph's %s", path, i, rec.name, L.name.c_str());
+            return RFD_ERR_INVALID_ARG;
+        }
+        const size_t nw = (size_t)L.cout * L.kh * L.kw * L.cin;
+        std::vector<float> w(nw), b(L.cout), sc(L.cout), sh(L.cout);
+        bool ok = fread(w.data(), 4, nw, f) == nw && fread(b.data(), 4, L.cout, f) == (size_t)L.cout;
+        if (ok && L.has_affine) ok = fread(sc.data(), 4, L.cout, f) == (size_t)L.cout && fread(sh.data(), 4, L.cout, f) == (size_t)L.cout;
+        if (!ok) { fclose(f); set_error("%s is truncated (layer %zu)", path, i); return RFD_ERR_IO; }
+        int st = c->net.set_layer((int)i, w.data(), b.data(), c->stream);
+        if (st == RFD_OK && L.has_affine) st = c->net.set_affine((int)i, sc.data(), sh.data(), c->stream);
+        if (st != RFD_OK) { fclose(f); return st; }
+    }
+    fclose(f);
+    c->net.weights_ready = true;
+    return RFD_OK;
+}
+
 // ---- hot path ----
 int rfd_detect_batch(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
 {

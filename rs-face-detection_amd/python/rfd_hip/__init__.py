@@ -91,7 +91,7 @@ API_SYMBOLS = [
     "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
     "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_selection_config_default",
-    "rfd_select_faces", "rfd_detect_select_batch",
+    "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
 ]
 
 _lib = None
@@ -150,6 +150,8 @@ def load_library(path=None):
     L.rfd_debug_tensor_io.argtypes = [vp, ci, ci, vp, ci]
     L.rfd_debug_run_ops.argtypes = [vp, ci, ci, ci]
     L.rfd_debug_set_conv_tile.argtypes = [vp, ci]
+    L.rfd_save_weights.argtypes = [vp, C.c_char_p]
+    L.rfd_load_weights.argtypes = [vp, C.c_char_p]
     L.rfd_selection_config_default.argtypes = [vp]
     L.rfd_selection_config_default.restype = None
     L.rfd_select_faces.argtypes = [vp, C.POINTER(rfd_dets), vp, vp, ci, vp, ci, vp, vp, vp]
@@ -256,6 +258,12 @@ class RetinaFaceDetection:
     # ---- weights ----
     def init_synthetic_weights(self, seed=1234):
         _check(self._L.rfd_init_synthetic_weights(self._ctx, seed))
+
+    def save_weights(self, path):
+        _check(self._L.rfd_save_weights(self._ctx, os.fsencode(path)))
+
+    def load_weights(self, path):
+        _check(self._L.rfd_load_weights(self._ctx, os.fsencode(path)))
 
     def get_layer(self, idx, desc):
         w = np.zeros((desc.cout, desc.kh, desc.kw, desc.cin), np.float32)  # depthwise: cin = 1

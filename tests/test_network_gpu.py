@@ -183,3 +183,32 @@ def test_uninitialised_weights_are_an_error(rfd):
         d.call(helpers.make_image(1, 64, 64))
     assert e.value.status == rfd.RFD_ERR_STATE
     d.close()
+
+
+def test_weight_file_roundtrip(rfd, tmp_path):
+    """rfd_save_weights -> rfd_load_weights into a fresh context reproduces the detections bit for bit;
+    a file of the other backbone or a truncated file is refused."""
+    a = rfd.RetinaFaceDetection(max_batch_size=1, max_det=256, backbone=rfd.BACKBONE_MNET025, confidence_threshold=0.3)
+    a.init_synthetic_weights(77)
+    frame = helpers.make_image(5, 480, 640)
+    want = a.call(frame)
+    path = str(tmp_path / "mnet.rfdw")
+    a.save_weights(path)
+    b = rfd.RetinaFaceDetection(max_batch_size=1, max_det=256, backbone=rfd.BACKBONE_MNET025, confidence_threshold=0.3)
+    b.load_weights(path)
+    got = b.call(frame)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and len(want[0]) > 0
+    c = rfd.RetinaFaceDetection(max_batch_size=1, backbone=rfd.BACKBONE_R50)
+    with pytest.raises(rfd.RfdError) as e:
+        c.load_weights(path)
+    assert e.value.status == rfd.RFD_ERR_INVALID_ARG
+    data = open(path, "rb").read()
+    open(path, "wb").write(data[: len(data) // 2])
+    with pytest.raises(rfd.RfdError) as e:
+        b.load_weights(path)
+    assert e.value.status == rfd.RFD_ERR_IO
+    with pytest.raises(rfd.RfdError) as e:
+        b.load_weights(str(tmp_path / "missing.rfdw"))
+    assert e.value.status == rfd.RFD_ERR_IO
+    for d in (a, b, c):
+        d.close()
