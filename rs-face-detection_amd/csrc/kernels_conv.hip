@@ -53,6 +53,110 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
 }
 constexpr uint32_t kOob = 0xfffffff0u; // >= any num_records: reads as zeros, touches no memory
 
+// residual prefetch (independent of the GEMM): 16 bytes = the lane's 8 channels of pixel (j)
+template <int TM, int TH, int WM, int WN>
+__device__ __forceinline__ void conv_prefetch_residual(const ConvParams &p, uint4 (&resv)[TM][TH], int m0, int n0, int wm,
+                                                       int wn, int frow, int fq, int M, int HoWo)
+{
+    if (!p.res) return;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + frow;
+        size_t mr = (size_t)(m < M ? m : 0);
+        if (p.res_up2 && m < M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+        }
+#pragma unroll
+        for (int h = 0; h < TH; ++h)
+            resv[j][h] = *reinterpret_cast<const uint4 *>(p.res + mr * p.Cout + n0 + wn * WN + h * 32 + fq * 8);
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[TN][TM], uint4 (&resv)[TM][TN / 2], int m0,
+                                              int n0, int wm, int wn, int frow, int fq, int M)
+{
+    constexpr int TH = TN / 2;
+    // ---- fused epilogue from registers: lane = pixel (j*16 + frow), channels h*32 + fq*8 .. +7 ----
+#pragma unroll
+    for (int h = 0; h < TH; ++h) {
+        const int n = n0 + wn * WN + h * 32 + fq * 8;
+        float bias[8], s2[8], t2[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+            if (p.bias2) {
+                const float4 d0 = *reinterpret_cast<const float4 *>(p.bias2 + n), d1 = *reinterpret_cast<const float4 *>(p.bias2 + n + 4);
+                bias[0] += d0.x; bias[1] += d0.y; bias[2] += d0.z; bias[3] += d0.w;
+                bias[4] += d1.x; bias[5] += d1.y; bias[6] += d1.z; bias[7] += d1.w;
+            }
+        }
+        if (p.y2) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(p.shift2 + n), c1 = *reinterpret_cast<const float4 *>(p.shift2 + n + 4);
+            s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
+            t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 16 + frow;
+            if (m >= M) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = acc[2 * h][j][k] + bias[k];
+                v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k];
+            }
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                const uint4 rv = resv[j][h];
+                r[0] = bf16_bits_to_f32(rv.x & 0xffffu); r[1] = bf16_bits_to_f32(rv.x >> 16);
+                r[2] = bf16_bits_to_f32(rv.y & 0xffffu); r[3] = bf16_bits_to_f32(rv.y >> 16);
+                r[4] = bf16_bits_to_f32(rv.z & 0xffffu); r[5] = bf16_bits_to_f32(rv.z >> 16);
+                r[6] = bf16_bits_to_f32(rv.w & 0xffffu); r[7] = bf16_bits_to_f32(rv.w >> 16);
+                if (!p.res_post) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += r[k];
+                }
+            }
+            if (p.y && n < p.n_valid) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
+                    if (p.res && p.res_post) o[k] += r[k];
+                }
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                const int nd = n + p.y_coff + (n >= p.y_split ? p.y_split_add : 0);
+                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + nd) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            if (p.y2) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                *reinterpret_cast<uint4 *>(p.y2 + (size_t)m * p.Cout + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            if (p.yf) {
+                if (p.head_softmax && n == 0) {
+                    // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
+                    const float m0s = fmaxf(v[0], v[2]), m1s = fmaxf(v[1], v[3]);
+                    const float e0 = expf(v[0] - m0s), e2 = expf(v[2] - m0s);
+                    const float e1 = expf(v[1] - m1s), e3 = expf(v[3] - m1s);
+                    v[0] = e0 / (e0 + e2); v[2] = e2 / (e0 + e2);
+                    v[1] = e1 / (e1 + e3); v[3] = e3 / (e1 + e3);
+                }
+                float4 *dst = reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n);
+                dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -169,23 +273,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 
     const int frow = lane & 15, fq = lane >> 4;
     constexpr int TH = TN / 2; // 8-channel groups per lane and pixel
-    // residual prefetch (independent of the GEMM): 16 bytes = the lane's 8 channels of pixel (j)
     uint4 resv[TM][TH];
-    if (p.res) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wm * WM + j * 16 + frow;
-            size_t mr = (size_t)(m < M ? m : 0);
-            if (p.res_up2 && m < M) {
-                const int b = m / HoWo, rem = m - b * HoWo;
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
-            }
-#pragma unroll
-            for (int h = 0; h < TH; ++h)
-                resv[j][h] = *reinterpret_cast<const uint4 *>(p.res + mr * p.Cout + n0 + wn * WN + h * 32 + fq * 8);
-        }
-    }
+    conv_prefetch_residual<TM, TH, WM, WN>(p, resv, m0, n0, wm, wn, frow, fq, M, HoWo);
 
     // optional input affine (+ReLU): per-channel scale/shift staged once in LDS behind the operand slots
     float *Sc = reinterpret_cast<float *>(Ws + (nk > 1 ? 2 : 1) * BN * 64);
@@ -259,82 +348,178 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         }
     }
 
-    // ---- fused epilogue from registers: lane = pixel (j*16 + frow), channels h*32 + fq*8 .. +7 ----
+    conv_epilogue<TM, TN, WM, WN>(p, acc, resv, m0, n0, wm, wn, frow, fq, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions with the three kx taps sharing ONE staged activation tile.
+//
+// The generic kernel above is LDS-DMA *issue* bound (8 one-KiB pieces per 32 MFMAs per wave; dropping the
+// activation DMA in a timing-only build made 3x3 layers 23-30 % faster).  For a 3x3 stride-1 conv the taps
+// (ky, kx = 0,1,2) of one 64-channel chunk read the same pixels shifted by ONE pixel, i.e. by one 128-byte
+// row of the flattened-pixel LDS tile.  So per (ky, chunk) one EXTENDED tile -- pixels m0-1 .. m0+158, 20
+// pieces -- is staged, and the three kx K-steps read their B fragments at row offsets 0 / 1 / 2; a fragment
+// whose pixel sits in image column 0 (kx = 0) or W-1 (kx = 2) would wrap into the neighbouring image row
+// and is zeroed in registers instead.  Activation pieces per three K-steps: 12 -> 5 per wave; the weight
+// tile streams as before.  K order: (ky, chunk, kx) -- only the f32 summation order differs.
+// LDS: 2 x 20 KiB activation slots + 2 weight slots: 72 KiB at BN = 128 -> two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const ConvParams p)
+{
+    constexpr int BM = 128, XE = 160; // extended tile rows (20 pieces)
+    constexpr int NW = WAVES_M * WAVES_N;
+    static_assert(NW == 4, "piece distribution assumes 4 waves");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int XPE = XE / 8 / NW, WP = (BN / 8 + NW - 1) / NW; // 5 activation pieces per wave and (ky, chunk)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem); // [2][XE*64]
+    bf16_t *Ws = Xs + 2 * XE * 64;                  // [2][BN*64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int HW = p.H * p.W;
+    const int M = p.B * HW;
+    const int K = 9 * p.Cin;
+    const int kc_n = p.Cin >> 6, ngroups = 3 * kc_n, nk = 3 * ngroups;
+    const int tiles_n = p.Cout / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * HW * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    // extended-tile row rho = piece*8 + lr holds pixel q = m0 - 1 + rho at input row y(q) + ky - 1
+    uint32_t xoff[XPE];
+    int y0[XPE];
 #pragma unroll
-    for (int h = 0; h < TH; ++h) {
-        const int n = n0 + wn * WN + h * 32 + fq * 8;
-        float bias[8], s2[8], t2[8];
-        {
-            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
-            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
-            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-            if (p.bias2) {
-                const float4 d0 = *reinterpret_cast<const float4 *>(p.bias2 + n), d1 = *reinterpret_cast<const float4 *>(p.bias2 + n + 4);
-                bias[0] += d0.x; bias[1] += d0.y; bias[2] += d0.z; bias[3] += d0.w;
-                bias[4] += d1.x; bias[5] += d1.y; bias[6] += d1.z; bias[7] += d1.w;
-            }
-        }
-        if (p.y2) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(p.scale2 + n), a1 = *reinterpret_cast<const float4 *>(p.scale2 + n + 4);
-            const float4 c0 = *reinterpret_cast<const float4 *>(p.shift2 + n), c1 = *reinterpret_cast<const float4 *>(p.shift2 + n + 4);
-            s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
-            t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
-        }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wm * WM + j * 16 + frow;
-            if (m >= M) continue;
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = acc[2 * h][j][k] + bias[k];
-                v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k];
-            }
-            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (p.res) {
-                const uint4 rv = resv[j][h];
-                r[0] = bf16_bits_to_f32(rv.x & 0xffffu); r[1] = bf16_bits_to_f32(rv.x >> 16);
-                r[2] = bf16_bits_to_f32(rv.y & 0xffffu); r[3] = bf16_bits_to_f32(rv.y >> 16);
-                r[4] = bf16_bits_to_f32(rv.z & 0xffffu); r[5] = bf16_bits_to_f32(rv.z >> 16);
-                r[6] = bf16_bits_to_f32(rv.w & 0xffffu); r[7] = bf16_bits_to_f32(rv.w >> 16);
-                if (!p.res_post) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += r[k];
-                }
-            }
-            if (p.y && n < p.n_valid) {
-                float o[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
-                    if (p.res && p.res_post) o[k] += r[k];
-                }
-                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                const int nd = n + p.y_coff + (n >= p.y_split ? p.y_split_add : 0);
-                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + nd) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-            if (p.y2) {
-                float o[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
-                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                *reinterpret_cast<uint4 *>(p.y2 + (size_t)m * p.Cout + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-            if (p.yf) {
-                if (p.head_softmax && n == 0) {
-                    // channels 0..3 = bg0,bg1,fg0,fg1: 2-class softmax over the pairs (a, A+a)
-                    const float m0s = fmaxf(v[0], v[2]), m1s = fmaxf(v[1], v[3]);
-                    const float e0 = expf(v[0] - m0s), e2 = expf(v[2] - m0s);
-                    const float e1 = expf(v[1] - m1s), e3 = expf(v[3] - m1s);
-                    v[0] = e0 / (e0 + e2); v[2] = e2 / (e0 + e2);
-                    v[1] = e1 / (e1 + e3); v[3] = e3 / (e1 + e3);
-                }
-                float4 *dst = reinterpret_cast<float4 *>(p.yf + (size_t)m * p.Cout + n);
-                dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-                dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-            }
+    for (int q = 0; q < XPE; ++q) {
+        const int pix = m0 - 1 + (wave + NW * q) * 8 + lr;
+        y0[q] = -(1 << 28);
+        xoff[q] = 0;
+        if (pix >= 0 && pix < M) {
+            const int b = pix / HW, rem = pix - b * HW;
+            const int y = rem / p.W, x = rem - y * p.W;
+            y0[q] = y - 1;
+            xoff[q] = (uint32_t)(((((long long)b * p.H + y - 1) * p.W + x) * p.ldx + p.x_coff + chunk * 8) * 2);
         }
     }
+    uint32_t woff[WP];
+#pragma unroll
+    for (int q = 0; q < WP; ++q) {
+        const int piece = wave + NW * q;
+        const int rho = (piece < BN / 8 ? piece * 8 + lr : 0);
+        const int rw_ = rho % WN, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        woff[q] = (uint32_t)(((size_t)(n0 + chn) * K + chunk * 8) * 2);
+    }
+    auto stage_x = [&](int slot, int ky, int kc) {
+        const uint32_t rowoff = (uint32_t)(ky * p.W * p.ldx * 2);
+#pragma unroll
+        for (int q = 0; q < XPE; ++q) {
+            const bool ok = (unsigned)(y0[q] + ky) < (unsigned)p.H;
+            blds16(rx, ok ? xoff[q] + rowoff : kOob, (uint32_t)(kc << 7), Xs + slot * XE * 64 + (wave + NW * q) * 512);
+        }
+    };
+    auto stage_w = [&](int slot, int ky, int kc, int kx) {
+        const uint32_t col = (uint32_t)((((ky * 3 + kx) * p.Cin) + (kc << 6)) * 2);
+#pragma unroll
+        for (int q = 0; q < WP; ++q) {
+            const int piece = wave + NW * q;
+            if (piece < BN / 8) blds16(rw, woff[q], col, Ws + slot * BN * 64 + piece * 512);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int TH = TN / 2;
+    uint4 resv[TM][TH];
+    conv_prefetch_residual<TM, TH, WM, WN>(p, resv, m0, n0, wm, wn, frow, fq, M, HW);
+    // fragment (j) is pixel m0 + wm*WM + j*16 + frow: column 0 kills the kx = 0 tap, column W-1 the kx = 2 tap
+    bool col_first[TM], col_last[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int x = (m0 + wm * WM + j * 16 + frow) % p.W;
+        col_first[j] = x == 0;
+        col_last[j] = x == p.W - 1;
+    }
+
+    // queue order: X(group 0), W(step 0)
+    stage_x(0, 0, 0);
+    stage_w(0, 0, 0, 0);
+    int ky = 0, kc = 0; // current group
+    int xslot = 0, wslot = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        int nky = ky, nkc = kc + 1; // next group
+        if (nkc == kc_n) { nkc = 0; ++nky; }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            // step (g, kx) needs W(this step) and X(g).  Only after the kx = 0 step are the XPE youngest DMAs
+            // (X(g+1), issued behind W) allowed to stay in flight across the barrier.
+            if (kx == 1 && g + 1 < ngroups) wait_vmcnt<XPE>();
+            else wait_vmcnt<0>();
+            asm volatile("s_barrier" ::: "memory");
+            if (kx < 2) stage_w(wslot ^ 1, ky, kc, kx + 1);
+            else if (g + 1 < ngroups) stage_w(wslot ^ 1, nky, nkc, 0);
+            if (kx == 0 && g + 1 < ngroups) stage_x(xslot ^ 1, nky, nkc);
+            const bf16_t *xs = Xs + xslot * XE * 64 + (wm * WM + kx) * 64; // tap kx: one LDS row further
+            const bf16_t *ws = Ws + wslot * BN * 64 + (wn * WN) * 64;
+            wslot ^= 1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[TN], bfr[TM];
+                const int ch = kk * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int r = i * 16 + frow;
+                    af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int r = j * 16 + frow;                    // row within the wave's slice
+                    const int rho = wm * WM + kx + r;               // LDS row of the extended tile: sets the swizzle
+                    bf16x8 v = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (rho & 7)) << 3));
+                    if ((kx == 0 && col_first[j]) || (kx == 2 && col_last[j])) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    bfr[j] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        xslot ^= 1;
+        ky = nky; kc = nkc;
+    }
+    conv_epilogue<TM, TN, WM, WN>(p, acc, resv, m0, n0, wm, wn, frow, fq, M);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int grid = ceil_div(M, 128) * (p.Cout / BN);
+    const size_t lds = (size_t)(2 * 160 + 2 * BN) * 64 * sizeof(bf16_t);
+    auto kern = conv3x3_kx_kernel<BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
@@ -376,6 +561,10 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     }
     const int M = p.B * p.Ho * p.Wo;
     const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
+    const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
+                       p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
+    if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);
+    // (with BN = 64 the merged-kx kernel measured 7 % slower than the generic 128x64 tile at 3 workgroups / CU)
     if (p.Cout % 128 == 0 && p.force_tile != 4) {
         // The 8-wave 256x128 tile with a 3-slot ring (1 workgroup per CU) measured 5-13 % SLOWER than two
         // co-resident 128x128 workgroups on every layer of this network (profiles/): opt-in only.
