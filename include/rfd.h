@@ -134,7 +134,8 @@ typedef struct rfd_layer_desc {
 typedef struct rfd_op_desc {
     int kind;  /* 0: conv0 7x7/2 + bias + ReLU, 1: maxpool 3x3/2 (+ affine + ReLU), 2: conv,
                   3: fused stem = kind 0 then kind 1 (conv0 result rounded to bf16 in between),
-                  4: depthwise 3x3 + bias + ReLU, 5: first 3x3/2 conv (3 input channels) + bias + ReLU */
+                  4: depthwise 3x3 + bias + ReLU, 5: first 3x3/2 conv (3 input channels) + bias + ReLU,
+                  6: back-to-back pair: kind 2 (out = raw sum) followed by out_b = relu(conv(relu(affine(out)), layer_b)) */
     int layer; /* weights used (kind 1: the layer whose affine is applied) */
     int in, out, out2, outf, res; /* tensor ids, -1 = none: out = bf16 result, out2 = relu(affine(v)),
                                      outf = f32 result (heads), res = residual input */
@@ -146,6 +147,7 @@ typedef struct rfd_op_desc {
     int x_coff;      /* the input is the channel slice [x_coff, x_coff + cin) of tensor `in` */
     int y_split, y_split_add; /* output channel n goes to y_coff + n (+ y_split_add if n >= y_split) */
     int n_valid;     /* only output channels < n_valid are stored */
+    int layer_b, out_b; /* kind 6: the next unit's conv1 applied to relu(affine(out)), and its output tensor */
 } rfd_op_desc;
 typedef struct rfd_tensor_desc {
     int channels, height, width; /* channels = device channels: channels_logical zero-padded (to 64) */

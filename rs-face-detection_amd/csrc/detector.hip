@@ -267,7 +267,7 @@ int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
         RFD_TRY(c->net.collect_profile());
         c->conv_ms = 0.f; c->conv_flops = 0.0; c->conv_launches = 0;
         for (size_t i = 0; i < c->net.g.ops.size(); ++i)
-            if (c->net.g.ops[i].kind == OP_CONV) {
+            if (c->net.g.ops[i].kind == OP_CONV || c->net.g.ops[i].kind == OP_B2B) {
                 c->conv_ms += c->net.op_ms[i];
                 c->conv_flops += 2.0 * c->net.g.layer_macs((int)i) * n;
                 ++c->conv_launches;
@@ -529,7 +529,7 @@ int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
     d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
     d->in2 = o.in2; d->layer2 = o.layer2; d->in_affine = o.in_affine;
     d->layer_n2 = o.layer_n2; d->x_coff = o.x_coff; d->y_split = o.y_split; d->y_split_add = o.y_split_add;
-    d->n_valid = o.n_valid;
+    d->n_valid = o.n_valid; d->layer_b = o.layer_b; d->out_b = o.out_b;
     d->macs = g->layer_macs(idx);
     return RFD_OK;
 }

@@ -109,6 +109,20 @@ struct ConvParams {
     int head_softmax;     // heads: channels [0,4) are cls logits -> 2-class softmax pairs (a, A+a)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);
+// back-to-back fusion (stage 1): raw = conv3(x) [+ 1x1 shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw*scale+shift)) + bias1)
+struct B2BParams {
+    const bf16_t *x, *x2;      // [M][Cin], optional [M][Cin2] (stride-1 shortcut source)
+    const bf16_t *w3;          // [256][Cin + Cin2]
+    const float *bias3, *bias3b; // conv3 bias, shortcut bias (or null)
+    const bf16_t *res;         // [M][256] or null
+    const float *scale, *shift; // the unit's post-add affine
+    bf16_t *raw;               // [M][256]
+    const bf16_t *w1;          // [64][256]
+    const float *bias1;
+    bf16_t *t1;                // [M][64]
+    int B, H, W, Cin, Cin2;
+};
+int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s);
 // conv0: 7x7 stride 2 pad 3 on the NHWC4 input, fused bias + ReLU -> [B][H/2][W/2][64]
 int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H,
                  int W, hipStream_t s);

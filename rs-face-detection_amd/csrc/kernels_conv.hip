@@ -522,6 +522,204 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
     return RFD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Back-to-back fusion for the pre-activation units of stage 1:
+//     raw = conv3(t2) [+ shortcut(act)] + bias (+ residual)      -> HBM (the next unit's residual)
+//     a   = relu(raw * scale + shift)                             -> bf16 operand tile in LDS only
+//     t1' = relu(conv1_next(a) + bias1)                           -> HBM
+// One 8-wave workgroup owns 128 pixels x all 256 channels, so the 1x1 "next conv1" (K = 256) can run on
+// the activated tile without it ever leaving the CU: the 419 MB tensor is written once (raw) and no longer
+// read by conv1.  Everything is resident in LDS: X k-tiles (16 KiB each, up to 2), W3 k-tiles (32 KiB each),
+// the 128 x 256 bf16 operand tile (64 KiB), W1 (32 KiB) -- 144 KiB for K1 = 64; for K1 = 128 (unit 1: fused
+// shortcut) the second X/W3 k-tile reuses the first one's slot behind a barrier.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
+{
+    constexpr int BM = 128, N1 = 256, N2 = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [128][64]
+    bf16_t *W3s = Xs + BM * 64;                      // [256][64]
+    bf16_t *A2 = W3s + N1 * 64;                      // [4][128][64]  k-tiles of the activated tile
+    bf16_t *W1s = A2 + 4 * BM * 64;                  // [4][64][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;        // phase 1: 2 (m) x 4 (n) waves, 64 x 64 each
+    const int HW = p.H * p.W, M = p.B * HW;
+    const int K1 = p.Cin + p.Cin2, nk1 = K1 >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.Cin2 ? p.x2 : p.x), 0,
+                                                                         (uint32_t)(p.Cin2 ? (size_t)M * p.Cin2 * 2 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w3), 0, (uint32_t)((size_t)N1 * K1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w1), 0, (uint32_t)((size_t)N2 * N1 * 2), 0x00020000);
+
+    // permuted channel map of an operand-A row (see conv_igemm_kernel): row rho of a 64-wide slice
+    auto perm64 = [](int rho) { const int i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3; return (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_; };
+    // ---- stage: X tile kt (2 pieces / wave), W3 tile kt (4 pieces / wave), and once W1 (4 pieces / wave) ----
+    auto stage1 = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = wave + 8 * q, m = m0 + piece * 8 + lr;
+            uint32_t off = kOob;
+            if (m < M) off = (uint32_t)(((size_t)m * (kt < (p.Cin >> 6) ? p.Cin : p.Cin2) + chunk * 8) * 2);
+            if (kt < (p.Cin >> 6)) blds16(rx, off, (uint32_t)(kt << 7), Xs + piece * 512);
+            else blds16(rx2, off, (uint32_t)((kt - (p.Cin >> 6)) << 7), Xs + piece * 512);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave + 8 * q, rho = piece * 8 + lr; // 0..255
+            const int chn = (rho & ~63) + perm64(rho & 63);
+            blds16(rw3, (uint32_t)(((size_t)chn * K1 + chunk * 8) * 2), (uint32_t)(kt << 7), W3s + piece * 512);
+        }
+    };
+    stage1(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { // W1: [4 k-tiles][64 rows][64]: piece = kt2*8 + (row/8)
+        const int piece = wave + 8 * q, kt2 = piece >> 3, rho = (piece & 7) * 8 + lr;
+        blds16(rw1, (uint32_t)(((size_t)perm64(rho) * N1 + chunk * 8) * 2), (uint32_t)(kt2 << 7), W1s + piece * 512);
+    }
+    // residual prefetch for this wave's 64 x 64 output slice: [j][h] = pixel j*16+frow, channels h*32+fq*8..+7
+    uint4 resv[4][2];
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + frow;
+            const size_t mr = (size_t)(m < M ? m : 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) resv[j][h] = *reinterpret_cast<const uint4 *>(p.res + mr * N1 + wn * 64 + h * 32 + fq * 8);
+        }
+    }
+
+    // ---- phase 1: acc1[64 n x 64 m per wave] over K1 ----
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk1; ++kt) {
+        wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        const bf16_t *xs = Xs + (wm * 64) * 64, *ws = W3s + (wn * 64) * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+            const int ch = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int r = i * 16 + frow; af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3)); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = j * 16 + frow; bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3)); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk1) {
+            asm volatile("s_barrier" ::: "memory"); // every wave is done with the slot
+            stage1(kt + 1);
+        }
+    }
+
+    // ---- epilogue 1: raw -> HBM, relu(affine(raw)) -> LDS operand tile (k-tile = wn, chunk = h*4 + fq) ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = wn * 64 + h * 32 + fq * 8;
+        float bias[8], s2[8], t2[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias3 + n), b1 = *reinterpret_cast<const float4 *>(p.bias3 + n + 4);
+            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+            if (p.bias3b) {
+                const float4 d0 = *reinterpret_cast<const float4 *>(p.bias3b + n), d1 = *reinterpret_cast<const float4 *>(p.bias3b + n + 4);
+                bias[0] += d0.x; bias[1] += d0.y; bias[2] += d0.z; bias[3] += d0.w; bias[4] += d1.x; bias[5] += d1.y; bias[6] += d1.z; bias[7] += d1.w;
+            }
+            const float4 a0 = *reinterpret_cast<const float4 *>(p.scale + n), a1 = *reinterpret_cast<const float4 *>(p.scale + n + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(p.shift + n), c1 = *reinterpret_cast<const float4 *>(p.shift + n + 4);
+            s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
+            t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wm * 64 + j * 16 + frow, m = m0 + row;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = acc[2 * h][j][k] + bias[k]; v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k]; }
+            if (p.res) {
+                const uint4 rv = resv[j][h];
+                v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                v[4] += bf16_bits_to_f32(rv.z & 0xffffu); v[5] += bf16_bits_to_f32(rv.z >> 16);
+                v[6] += bf16_bits_to_f32(rv.w & 0xffffu); v[7] += bf16_bits_to_f32(rv.w >> 16);
+            }
+            const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+            if (m < M) *reinterpret_cast<uint4 *>(p.raw + (size_t)m * N1 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            // the consumer conv1 sees relu(affine(bf16(raw))): same rounding points as the unfused pair
+            float a[8];
+            const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[2 * k] = fmaxf(bf16_bits_to_f32(rb[k] & 0xffffu) * s2[2 * k] + t2[2 * k], 0.f);
+                a[2 * k + 1] = fmaxf(bf16_bits_to_f32(rb[k] >> 16) * s2[2 * k + 1] + t2[2 * k + 1], 0.f);
+            }
+            const uint2 alo = pack_bf16x4(a[0], a[1], a[2], a[3]), ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+            const int c = h * 4 + fq;
+            *reinterpret_cast<uint4 *>(A2 + wn * BM * 64 + row * 64 + ((c ^ (row & 7)) << 3)) = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+        }
+    }
+    wait_vmcnt<0>(); // W1 has landed (issued first)
+    __syncthreads();
+
+    // ---- phase 2: t1[16 pixels x 64 channels per wave] = A2[128 x 256] . W1^T ----
+    f32x4 acc2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = kk * 4 + fq;
+            const int r = wave * 16 + frow;
+            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(A2 + kt2 * BM * 64 + r * 64 + ((ch ^ (r & 7)) << 3));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = i * 16 + frow;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(W1s + kt2 * N2 * 64 + ra * 64 + ((ch ^ (ra & 7)) << 3));
+                acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc2[i], 0, 0, 0);
+            }
+        }
+    }
+    const int m = m0 + wave * 16 + frow;
+    if (m < M) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = h * 32 + fq * 8;
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias1 + n), b1 = *reinterpret_cast<const float4 *>(p.bias1 + n + 4);
+            const uint2 lo = pack_bf16x4(fmaxf(acc2[2 * h][0] + b0.x, 0.f), fmaxf(acc2[2 * h][1] + b0.y, 0.f), fmaxf(acc2[2 * h][2] + b0.z, 0.f), fmaxf(acc2[2 * h][3] + b0.w, 0.f));
+            const uint2 hi = pack_bf16x4(fmaxf(acc2[2 * h + 1][0] + b1.x, 0.f), fmaxf(acc2[2 * h + 1][1] + b1.y, 0.f), fmaxf(acc2[2 * h + 1][2] + b1.z, 0.f), fmaxf(acc2[2 * h + 1][3] + b1.w, 0.f));
+            *reinterpret_cast<uint4 *>(p.t1 + (size_t)m * N2 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+
+int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
+{
+    if (p.Cin != 64 || (p.Cin2 != 0 && p.Cin2 != 64)) {
+        set_error("b2b: unsupported shape Cin=%d Cin2=%d", p.Cin, p.Cin2);
+        return RFD_ERR_INVALID_ARG;
+    }
+    const int M = p.B * p.H * p.W;
+    const size_t lds = (size_t)(128 * 64 + 256 * 64 + 4 * 128 * 64 + 4 * 64 * 64) * sizeof(bf16_t); // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_b2b_s1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_b2b_s1_kernel, dim3(ceil_div(M, 128)), dim3(512), lds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
 static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
 {

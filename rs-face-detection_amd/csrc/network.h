@@ -25,7 +25,7 @@ struct Layer {
     size_t a_off;   // float offset of the post-add affine: scale [cout] then shift [cout] (has_affine only)
 };
 
-enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2, OP_STEM = 3, OP_DW = 4, OP_FIRST = 5 };
+enum OpKind { OP_CONV0 = 0, OP_POOL = 1, OP_CONV = 2, OP_STEM = 3, OP_DW = 4, OP_FIRST = 5, OP_B2B = 6 };
 
 struct Op {
     int kind;
@@ -37,6 +37,7 @@ struct Op {
     int x_coff;                   // the input is the channel slice [x_coff, x_coff+cin) of tensor `in`
     int y_split, y_split_add;     // output channels >= y_split are stored y_split_add channels further
     int n_valid;                  // only output channels < n_valid are stored (padded weight rows)
+    int layer_b, out_b;           // OP_B2B: the NEXT unit's conv1 (applied to relu(affine(out))) and its output tensor
     int relu, res_up2, res_post, head_softmax, y_coff;
 };
 

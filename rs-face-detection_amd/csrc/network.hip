@@ -56,6 +56,7 @@ int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int
     o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
     o.in2 = -1; o.layer2 = -1; o.in_affine = -1;
     o.layer_n2 = -1; o.x_coff = 0; o.y_split = 1 << 30; o.y_split_add = 0; o.n_valid = 1 << 30;
+    o.layer_b = -1; o.out_b = -1;
     o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
     ops.push_back(o);
     return (int)ops.size() - 1;
@@ -73,13 +74,14 @@ void Graph::build_r50()
     // stem: conv0 + BN + ReLU + max pool + BN1 + ReLU as ONE kernel (the 320x320x64 conv0 activation stays on chip)
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 1, 0, 0, 0, 0};
+        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
     static const int mids[4] = {64, 128, 256, 512};
     int x_act = t_p, x_raw = -1, cin = 64, h = H / 4, w = W / 4;
     int prev_l3 = -1; // conv3 layer of the previous unit when its BN+ReLU output was NOT materialised
+    int b2b_t1 = -1;  // conv1 output already produced by the previous unit's back-to-back kernel
     int c_out[4] = {-1, -1, -1, -1};
     for (int s = 0; s < 4; ++s) {
         const int mid = mids[s], cout = mid * 4;
@@ -88,10 +90,12 @@ void Graph::build_r50()
             const bool dim_match = u > 0;
             const int ho = h / stride, wo = w / stride;
             char nm[64];
-            snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 1);
-            const int l1 = add_layer(nm, cin, mid, 1, 1, 0, 1.0f, 0);
-            const int t1 = add_tensor(mid, h, w);
-            {
+            int t1 = b2b_t1; // stage 1: this unit's conv1 already ran inside the previous unit's back-to-back kernel
+            b2b_t1 = -1;
+            if (t1 < 0) {
+                snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 1);
+                const int l1 = add_layer(nm, cin, mid, 1, 1, 0, 1.0f, 0);
+                t1 = add_tensor(mid, h, w);
                 // inside a stage the previous unit stores only its raw sum; its BN+ReLU ("act") is applied
                 // to this conv's input fragments on the fly instead of round-tripping a second tensor
                 const int o1 = add_conv(l1, x_act >= 0 ? x_act : x_raw, t1, 1);
@@ -119,6 +123,14 @@ void Graph::build_r50()
             const int t_act = (last || !fuse_act) ? add_tensor(cout, ho, wo) : -1;
             const int o3 = add_conv(l3, t2, t_raw, 0, dim_match ? x_raw : -1, t_act);
             if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
+            if (s == 0 && !last) {
+                // stage 1: conv3 of this unit and conv1 of the NEXT unit run back to back in one kernel; the
+                // activated 256-channel tile stays in LDS (conv_b2b_s1_kernel)
+                snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 2);
+                const int l1n = add_layer(nm, cout, mid, 1, 1, 0, 1.0f, 0);
+                b2b_t1 = add_tensor(mid, ho, wo);
+                ops[o3].kind = OP_B2B; ops[o3].layer_b = l1n; ops[o3].out_b = b2b_t1;
+            }
             x_raw = t_raw; x_act = t_act; prev_l3 = l3; cin = cout; h = ho; w = wo;
         }
         c_out[s] = x_act;
@@ -194,7 +206,7 @@ void Graph::build_mnet025()
     input = add_tensor(4, H, W);
     auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
     auto simple_op = [&](int kind, int layer, int in, int out) {
-        Op o{kind, layer, in, out, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 1, 0, 0, 0, 0};
+        Op o{kind, layer, in, out, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     };
     int h = H / 2, w = W / 2;
@@ -270,6 +282,7 @@ void Graph::plan()
         touch(o.out, i, true);
         touch(o.out2, i, true);
         touch(o.outf, i, true);
+        touch(o.out_b, i, true);
     }
     for (int l = 0; l < 3; ++l) tensors[heads[l]].last = nops; // consumed by decode after the net
     buffer_bytes_per_image.clear();
@@ -302,6 +315,7 @@ void Graph::plan()
         if (o.out >= 0) assign(o.out);
         if (o.out2 >= 0) assign(o.out2);
         if (o.outf >= 0) assign(o.outf);
+        if (o.out_b >= 0) assign(o.out_b);
     }
 }
 
@@ -335,6 +349,7 @@ double Graph::layer_macs(int i) const
     double m = (double)tensors[t].H * tensors[t].W * L.cout * L.kh * L.kw * L.cin;
     if (o.layer2 >= 0) m += (double)tensors[t].H * tensors[t].W * L.cout * layers[o.layer2].cin;
     if (o.layer_n2 >= 0) m += (double)tensors[t].H * tensors[t].W * layers[o.layer_n2].cout * L.kh * L.kw * L.cin;
+    if (o.layer_b >= 0) m += (double)tensors[t].H * tensors[t].W * layers[o.layer_b].cout * layers[o.layer_b].cin;
     return m;
 }
 
@@ -589,6 +604,28 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         } else if (o.kind == OP_STEM) {
             RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
                                 d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+        } else if (o.kind == OP_B2B) {
+            const Layer &Lb = g.layers[o.layer_b];
+            B2BParams bp;
+            memset(&bp, 0, sizeof bp);
+            bp.x = (const bf16_t *)tensor_ptr(o.in);
+            bp.w3 = d_w + L.w_off;
+            bp.bias3 = d_b + L.b_off;
+            if (o.layer2 >= 0) {
+                const Layer &L2 = g.layers[o.layer2];
+                bp.x2 = (const bf16_t *)tensor_ptr(o.in2);
+                bp.bias3b = d_b + L2.b_off;
+                bp.Cin2 = L2.cin_d;
+            }
+            bp.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
+            bp.scale = d_b + g.b_total + L.a_off;
+            bp.shift = d_b + g.b_total + L.a_off + L.cout_d;
+            bp.raw = (bf16_t *)tensor_ptr(o.out);
+            bp.w1 = d_w + Lb.w_off;
+            bp.bias1 = d_b + Lb.b_off;
+            bp.t1 = (bf16_t *)tensor_ptr(o.out_b);
+            bp.B = B; bp.H = tin.H; bp.W = tin.W; bp.Cin = L.cin_d;
+            RFD_TRY(launch_conv_b2b_s1(bp, s));
         } else if (o.kind == OP_POOL) {
             RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
                                         d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout_d, B, tin.H, tin.W,

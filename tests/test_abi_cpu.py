@@ -33,11 +33,13 @@ def test_exports_only_the_c_abi(rfd):
 def test_graph_matches_survey_appendix_b(rfd):
     g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
     assert abs(g.macs - 44.2646528e9) < 1e3          # 44.265 GMAC / image
-    convs = [o for o in g.ops if o.kind in (0, 2, 3)]
+    convs = [o for o in g.ops if o.kind in (0, 2, 3, 6)]
     heads = [o for o in g.ops if o.head_softmax]
     fused_sc = [o for o in g.ops if o.layer2 >= 0]     # 4 shortcut convs ride in their conv3's GEMM
     fused_n = [o for o in g.ops if o.layer_n2 >= 0]    # 6 SSH sibling pairs run as one GEMM along N
-    assert len(convs) + 2 * len(heads) + len(fused_sc) + len(fused_n) == 82  # 9 head convs = 3 fused N=32 GEMMs
+    b2b = [o for o in g.ops if o.kind == 6]             # conv3 + next conv1 back to back (stage 1)
+    assert len(convs) + 2 * len(heads) + len(fused_sc) + len(fused_n) + len(b2b) == 82  # 9 head convs = 3 fused N=32 GEMMs
+    assert len(b2b) == 2
     assert len(fused_n) == 6
     assert len(fused_sc) == 4 and g.num_layers == 76
     assert sorted(t.head_level for t in g.tensors if t.head_level) == [1, 2, 3]
@@ -54,7 +56,7 @@ def test_graph_plan_has_no_aliasing(rfd):
     g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
     # tensors that share a buffer must have disjoint live ranges: an op never reads and writes one buffer
     for o in g.ops:
-        outs = [t for t in (o.out, o.out2, o.outf) if t >= 0]
+        outs = [t for t in (o.out, o.out2, o.outf, o.out_b) if t >= 0]
         ins = [t for t in (o.in_, o.in2, o.res) if t >= 0]
         ob = [g.tensors[t].buffer for t in outs]
         assert len(set(ob)) == len(ob)

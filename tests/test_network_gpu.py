@@ -57,7 +57,7 @@ def test_every_op_in_isolation(rfd, net, tile):
     n = 2
     exact = []
     for i, o in enumerate(g.ops):
-        if tile == 2 and (o.kind != 2 or g.layers[o.layer].cout % 128 or o.layer_n2 >= 0):
+        if tile == 2 and (o.kind != 2 or g.layers[o.layer].cout % 128 or o.layer_n2 >= 0):  # (kind 6 has its own kernel)
             continue
         tens = {}
         tin = g.tensors[o.in_]
@@ -81,7 +81,7 @@ def test_every_op_in_isolation(rfd, net, tile):
         det.debug_run(n, i, i)
         with torch.no_grad():
             ref.run_op(i, tens)
-        for t in (o.out, o.out2, o.outf):
+        for t in (o.out, o.out2, o.outf, o.out_b):
             if t < 0:
                 continue
             td = g.tensors[t]

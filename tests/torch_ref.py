@@ -95,6 +95,10 @@ class TorchRef:
         if o.out2 >= 0:
             s, t = self.aff[o.layer]
             tensors[o.out2] = bf16r(F.relu(v * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+        if o.kind == 6:  # back to back: the next unit's conv1 on relu(affine(bf16 raw)), bias + relu
+            s, tt = self.aff[o.layer]
+            a = bf16r(F.relu(tensors[o.out] * s.view(1, -1, 1, 1) + tt.view(1, -1, 1, 1)))
+            tensors[o.out_b] = bf16r(F.relu(F.conv2d(a, self.w[o.layer_b], self.b[o.layer_b])))
         if o.outf >= 0:
             if o.head_softmax:  # channels 0,1 = bg(a), 2,3 = fg(a): softmax over the pairs (a, A+a)
                 pr = torch.softmax(torch.stack([v[:, 0:2], v[:, 2:4]], 0), 0)
