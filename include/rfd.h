@@ -147,6 +147,7 @@ typedef struct rfd_op_desc {
     int x_coff;      /* the input is the channel slice [x_coff, x_coff + cin) of tensor `in` */
     int y_split, y_split_add; /* output channel n goes to y_coff + n (+ y_split_add if n >= y_split) */
     int n_valid;     /* only output channels < n_valid are stored */
+    int branch;      /* 0 main chain; 1, 2: independent side chains that run on their own HIP streams */
     int layer_b, out_b; /* kind 6: the next unit's conv1 applied to relu(affine(out)), and its output tensor */
 } rfd_op_desc;
 typedef struct rfd_tensor_desc {

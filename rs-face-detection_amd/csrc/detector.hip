@@ -529,7 +529,7 @@ int rfd_graph_op(const rfd_graph *gg, int idx, rfd_op_desc *d)
     d->head_softmax = o.head_softmax; d->y_coff = o.y_coff;
     d->in2 = o.in2; d->layer2 = o.layer2; d->in_affine = o.in_affine;
     d->layer_n2 = o.layer_n2; d->x_coff = o.x_coff; d->y_split = o.y_split; d->y_split_add = o.y_split_add;
-    d->n_valid = o.n_valid; d->layer_b = o.layer_b; d->out_b = o.out_b;
+    d->n_valid = o.n_valid; d->layer_b = o.layer_b; d->out_b = o.out_b; d->branch = o.branch;
     d->macs = g->layer_macs(idx);
     return RFD_OK;
 }

@@ -37,6 +37,7 @@ struct Op {
     int x_coff;                   // the input is the channel slice [x_coff, x_coff+cin) of tensor `in`
     int y_split, y_split_add;     // output channels >= y_split are stored y_split_add channels further
     int n_valid;                  // only output channels < n_valid are stored (padded weight rows)
+    int branch;                   // 0 = main stream; 1, 2 = independent side chains (SSH + head of stride 32 / 16)
     int layer_b, out_b;           // OP_B2B: the NEXT unit's conv1 (applied to relu(affine(out))) and its output tensor
     int relu, res_up2, res_post, head_softmax, y_coff;
 };
@@ -104,6 +105,11 @@ struct Network {
     std::vector<hipGraphExec_t> graph_exec; // indexed by B
     std::vector<char> warmed;               // eager run done for this B (one-time kernel attribute set-up)
     bool use_graph = true;
+    // side streams: the stride-32 / stride-16 SSH + head chains have tiny grids and no dependency on the stride-8
+    // chain, so they run concurrently with it (fork after their FPN input, join at the end of the pass)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    bool multi_stream = true;
     int collect_profile(); // after the stream has drained
 };
 

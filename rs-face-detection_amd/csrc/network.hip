@@ -56,7 +56,7 @@ int Graph::add_conv(int layer, int in, int out, int relu, int res, int out2, int
     o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.out2 = out2; o.outf = outf; o.res = res;
     o.in2 = -1; o.layer2 = -1; o.in_affine = -1;
     o.layer_n2 = -1; o.x_coff = 0; o.y_split = 1 << 30; o.y_split_add = 0; o.n_valid = 1 << 30;
-    o.layer_b = -1; o.out_b = -1;
+    o.layer_b = -1; o.out_b = -1; o.branch = 0;
     o.relu = relu; o.res_up2 = 0; o.res_post = 0; o.head_softmax = 0; o.y_coff = 0;
     ops.push_back(o);
     return (int)ops.size() - 1;
@@ -74,7 +74,7 @@ void Graph::build_r50()
     // stem: conv0 + BN + ReLU + max pool + BN1 + ReLU as ONE kernel (the 320x320x64 conv0 activation stays on chip)
     const int t_p = add_tensor(64, H / 4, W / 4);
     {
-        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, -1, -1, 1, 0, 0, 0, 0};
+        Op o{OP_STEM, l0, input, t_p, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 0, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
@@ -135,38 +135,17 @@ void Graph::build_r50()
         }
         c_out[s] = x_act;
     }
-    // FPN (c1 = stage2 out @ /8, c2 = stage3 out @ /16, c3 = stage4 out @ /32)
-    const int c1 = c_out[1], c2 = c_out[2], c3 = c_out[3];
-    auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
-    const int lat3 = add_layer("fpn_lat3", 2048, 256, 1, 1, 0, 1.0f, 0);
-    const int p3 = add_tensor(256, T(c3).H, T(c3).W);
-    add_conv(lat3, c3, p3, 1);
-    const int lat2 = add_layer("fpn_lat2", 1024, 256, 1, 1, 0, 1.0f, 0);
-    const int p2pre = add_tensor(256, T(c2).H, T(c2).W);
-    {
-        const int o = add_conv(lat2, c2, p2pre, 1, p3);
-        ops[o].res_up2 = 1; ops[o].res_post = 1;
-    }
-    const int ag2 = add_layer("fpn_aggr2", 256, 256, 3, 1, 1, 0.8f, 0);
-    const int p2 = add_tensor(256, T(c2).H, T(c2).W);
-    add_conv(ag2, p2pre, p2, 1);
-    const int lat1 = add_layer("fpn_lat1", 512, 256, 1, 1, 0, 1.0f, 0);
-    const int p1pre = add_tensor(256, T(c1).H, T(c1).W);
-    {
-        const int o = add_conv(lat1, c1, p1pre, 1, p2);
-        ops[o].res_up2 = 1; ops[o].res_post = 1;
-    }
-    const int ag1 = add_layer("fpn_aggr1", 256, 256, 3, 1, 1, 0.8f, 0);
-    const int p1 = add_tensor(256, T(c1).H, T(c1).W);
-    add_conv(ag1, p1pre, p1, 1);
-
-    // SSH context module + fused heads per level, order = reference slot order 32,16,8.
-    // One 384-channel buffer O = [b1 0:128 | b2 128:192 | b3 192:256 | tc 256:320 | td 320:384]; sibling convs
+    // FPN (c1 = stage2 out @ /8, c2 = stage3 out @ /16, c3 = stage4 out @ /32), each level immediately followed by
+    // its SSH context module + fused heads (reference slot order 32,16,8).  The stride-32 and stride-16 chains are
+    // side branches: small grids, independent of everything after them -> they overlap the stride-8 work.
+    // SSH: one 384-channel buffer O = [b1 0:128 | b2 128:192 | b3 192:256 | tc 256:320 | td 320:384]; sibling convs
     // that share an input run as ONE GEMM along N:  {conv1, ctx1}(f) -> b1 | tc ;  {ctx2, ctx3a}(tc) -> b2 | td ;
     // ctx3b(td) -> b3 ;  heads read the concat O[:, 0:256].  (All five carry the post-concat ReLU.)
-    const int feats[3] = {p3, p2, p1};
-    for (int l = 0; l < 3; ++l) {
-        const int f = feats[l], fh = T(f).H, fw = T(f).W, st = kStrides[l];
+    const int c1 = c_out[1], c2 = c_out[2], c3 = c_out[3];
+    auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
+    auto ssh_and_head = [&](int l, int f, int branch) {
+        const int fh = T(f).H, fw = T(f).W, st = kStrides[l];
+        const size_t first = ops.size();
         char nm[64];
         const int o = add_tensor(384, fh, fw);
         snprintf(nm, sizeof nm, "ssh%d_conv1", st);
@@ -193,7 +172,32 @@ void Graph::build_r50()
         snprintf(nm, sizeof nm, "head%d", st);
         heads[l] = add_tensor(32, fh, fw, 1);
         ops[add_conv(add_layer(nm, 256, 32, 1, 1, 0, 1.0f, 0), o, -1, 0, -1, -1, heads[l])].head_softmax = 1;
+        for (size_t i = first; i < ops.size(); ++i) ops[i].branch = branch;
+    };
+    const int lat3 = add_layer("fpn_lat3", 2048, 256, 1, 1, 0, 1.0f, 0);
+    const int p3 = add_tensor(256, T(c3).H, T(c3).W);
+    add_conv(lat3, c3, p3, 1);
+    ssh_and_head(0, p3, 1);
+    const int lat2 = add_layer("fpn_lat2", 1024, 256, 1, 1, 0, 1.0f, 0);
+    const int p2pre = add_tensor(256, T(c2).H, T(c2).W);
+    {
+        const int o = add_conv(lat2, c2, p2pre, 1, p3);
+        ops[o].res_up2 = 1; ops[o].res_post = 1;
     }
+    const int ag2 = add_layer("fpn_aggr2", 256, 256, 3, 1, 1, 0.8f, 0);
+    const int p2 = add_tensor(256, T(c2).H, T(c2).W);
+    add_conv(ag2, p2pre, p2, 1);
+    ssh_and_head(1, p2, 2);
+    const int lat1 = add_layer("fpn_lat1", 512, 256, 1, 1, 0, 1.0f, 0);
+    const int p1pre = add_tensor(256, T(c1).H, T(c1).W);
+    {
+        const int o = add_conv(lat1, c1, p1pre, 1, p2);
+        ops[o].res_up2 = 1; ops[o].res_post = 1;
+    }
+    const int ag1 = add_layer("fpn_aggr1", 256, 256, 3, 1, 1, 0.8f, 0);
+    const int p1 = add_tensor(256, T(c1).H, T(c1).W);
+    add_conv(ag1, p1pre, p1, 1);
+    ssh_and_head(2, p1, 0);
 }
 
 // RetinaFace-MobileNet-0.25 (BASELINE.json configs[1]): MobileNetV1 x0.25 backbone (first 3x3/2 conv, 13
@@ -206,7 +210,7 @@ void Graph::build_mnet025()
     input = add_tensor(4, H, W);
     auto T = [&](int t) -> TensorDesc & { return tensors[t]; };
     auto simple_op = [&](int kind, int layer, int in, int out) {
-        Op o{kind, layer, in, out, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, -1, -1, 1, 0, 0, 0, 0};
+        Op o{kind, layer, in, out, -1, -1, -1, -1, -1, -1, -1, 0, 1 << 30, 0, 1 << 30, 0, -1, -1, 1, 0, 0, 0, 0};
         ops.push_back(o);
     };
     int h = H / 2, w = W / 2;
@@ -229,21 +233,12 @@ void Graph::build_mnet025()
         if (i == 10) c2 = x;  // 128 ch @ /16
         if (i == 12) c3 = x;  // 256 ch @ /32
     }
-    // FPN, 64 channels
-    const int p3 = add_tensor(64, T(c3).H, T(c3).W);
-    add_conv(add_layer("fpn_lat3", 256, 64, 1, 1, 0, 1.0f, 0), c3, p3, 1);
-    const int p2pre = add_tensor(64, T(c2).H, T(c2).W);
-    { const int o = add_conv(add_layer("fpn_lat2", 128, 64, 1, 1, 0, 1.0f, 0), c2, p2pre, 1, p3); ops[o].res_up2 = 1; ops[o].res_post = 1; }
-    const int p2 = add_tensor(64, T(c2).H, T(c2).W);
-    add_conv(add_layer("fpn_aggr2", 64, 64, 3, 1, 1, 0.8f, 0), p2pre, p2, 1);
-    const int p1pre = add_tensor(64, T(c1).H, T(c1).W);
-    { const int o = add_conv(add_layer("fpn_lat1", 64, 64, 1, 1, 0, 1.0f, 0), c1, p1pre, 1, p2); ops[o].res_up2 = 1; ops[o].res_post = 1; }
-    const int p1 = add_tensor(64, T(c1).H, T(c1).W);
-    add_conv(add_layer("fpn_aggr1", 64, 64, 3, 1, 1, 0.8f, 0), p1pre, p1, 1);
+    // FPN (64 channels), each level immediately followed by its SSH + head chain; the stride-32 / stride-16 chains
+    // are side branches (own streams), as in the R50 graph.
     // SSH: O[64] = [conv1 0:32 | ctx2 32:48 | ctx3b 48:64], ctx1: 64 -> 16, ctx3a: 16 -> 16; ReLU after concat
-    const int feats[3] = {p3, p2, p1};
-    for (int l = 0; l < 3; ++l) {
-        const int f = feats[l], fh = T(f).H, fw = T(f).W, st = kStrides[l];
+    auto ssh_and_head = [&](int l, int f, int branch) {
+        const int fh = T(f).H, fw = T(f).W, st = kStrides[l];
+        const size_t first = ops.size();
         char nm[64];
         const int o = add_tensor(64, fh, fw);
         snprintf(nm, sizeof nm, "ssh%d_conv1", st);
@@ -261,7 +256,21 @@ void Graph::build_mnet025()
         snprintf(nm, sizeof nm, "head%d", st);
         heads[l] = add_tensor(32, fh, fw, 1);
         ops[add_conv(add_layer(nm, 64, 32, 1, 1, 0, 1.0f, 0), o, -1, 0, -1, -1, heads[l])].head_softmax = 1;
-    }
+        for (size_t i = first; i < ops.size(); ++i) ops[i].branch = branch;
+    };
+    const int p3 = add_tensor(64, T(c3).H, T(c3).W);
+    add_conv(add_layer("fpn_lat3", 256, 64, 1, 1, 0, 1.0f, 0), c3, p3, 1);
+    ssh_and_head(0, p3, 1);
+    const int p2pre = add_tensor(64, T(c2).H, T(c2).W);
+    { const int o = add_conv(add_layer("fpn_lat2", 128, 64, 1, 1, 0, 1.0f, 0), c2, p2pre, 1, p3); ops[o].res_up2 = 1; ops[o].res_post = 1; }
+    const int p2 = add_tensor(64, T(c2).H, T(c2).W);
+    add_conv(add_layer("fpn_aggr2", 64, 64, 3, 1, 1, 0.8f, 0), p2pre, p2, 1);
+    ssh_and_head(1, p2, 2);
+    const int p1pre = add_tensor(64, T(c1).H, T(c1).W);
+    { const int o = add_conv(add_layer("fpn_lat1", 64, 64, 1, 1, 0, 1.0f, 0), c1, p1pre, 1, p2); ops[o].res_up2 = 1; ops[o].res_post = 1; }
+    const int p1 = add_tensor(64, T(c1).H, T(c1).W);
+    add_conv(add_layer("fpn_aggr1", 64, 64, 3, 1, 1, 0.8f, 0), p1pre, p1, 1);
+    ssh_and_head(2, p1, 0);
 }
 
 void Graph::plan()
@@ -285,6 +294,15 @@ void Graph::plan()
         touch(o.out_b, i, true);
     }
     for (int l = 0; l < 3; ++l) tensors[heads[l]].last = nops; // consumed by decode after the net
+    // side-branch ops run concurrently with later main-stream ops: everything they read or write keeps its buffer
+    // to the end of the pass (no reuse in either direction)
+    for (int i = 0; i < nops; ++i) {
+        const Op &o = ops[i];
+        if (!o.branch) continue;
+        const int ts[7] = {o.in, o.in2, o.res, o.out, o.out2, o.outf, o.out_b};
+        for (int t : ts)
+            if (t >= 0) tensors[t].last = nops;
+    }
     buffer_bytes_per_image.clear();
     std::vector<int> free_list;
     auto assign = [&](int t) {
@@ -371,6 +389,11 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     RFD_HIP(hipMalloc((void **)&d_b, (g.b_total + g.a_total) * sizeof(float))); // biases, then affines
     RFD_HIP(hipMemset(d_w, 0, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMemset(d_b, 0, (g.b_total + g.a_total) * sizeof(float)));
+    for (int i = 0; i < 2; ++i) {
+        RFD_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+        RFD_HIP(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
+        RFD_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    }
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
@@ -390,6 +413,12 @@ void Network::destroy()
     d_zero = nullptr;
     for (void *p : d_buffers)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (side[i]) (void)hipStreamDestroy(side[i]);
+        if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        side[i] = nullptr; ev_fork[i] = ev_join[i] = nullptr;
+    }
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (hipGraphExec_t ge : graph_exec)
         if (ge) (void)hipGraphExecDestroy(ge);
@@ -587,10 +616,23 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
     }
     if (last_op < 0 || last_op >= nops) last_op = nops - 1;
     prof_first = std::max(first_op, 0); prof_last = last_op;
+    hipStream_t main_stream = s;
+    const bool fork_ok = multi_stream && !profiling && first_op <= 0 && last_op == nops - 1 && side[0] && side[1];
+    bool forked[2] = {false, false};
     for (int i = std::max(first_op, 0); i <= last_op; ++i) {
         const Op &o = g.ops[i];
         const Layer &L = g.layers[o.layer];
         const TensorDesc &tin = g.tensors[o.in];
+        s = main_stream;
+        if (fork_ok && o.branch > 0) {
+            const int bidx = o.branch - 1;
+            if (!forked[bidx]) { // everything this chain reads was enqueued on the main stream before this point
+                RFD_HIP(hipEventRecord(ev_fork[bidx], main_stream));
+                RFD_HIP(hipStreamWaitEvent(side[bidx], ev_fork[bidx], 0));
+                forked[bidx] = true;
+            }
+            s = side[bidx];
+        }
         if (profiling) RFD_HIP(hipEventRecord(ev[2 * i], s));
         if (o.kind == OP_CONV0) {
             RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off,
@@ -670,6 +712,11 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         }
         if (profiling) RFD_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
+    for (int bidx = 0; bidx < 2; ++bidx)
+        if (forked[bidx]) { // join
+            RFD_HIP(hipEventRecord(ev_join[bidx], side[bidx]));
+            RFD_HIP(hipStreamWaitEvent(main_stream, ev_join[bidx], 0));
+        }
     return RFD_OK;
 }
 

@@ -72,7 +72,8 @@ class rfd_op_desc(C.Structure):
                 ("res_up2", C.c_int), ("res_post", C.c_int), ("head_softmax", C.c_int),
                 ("y_coff", C.c_int), ("macs", C.c_double), ("in2", C.c_int), ("layer2", C.c_int),
                 ("in_affine", C.c_int), ("layer_n2", C.c_int), ("x_coff", C.c_int), ("y_split", C.c_int),
-                ("y_split_add", C.c_int), ("n_valid", C.c_int), ("layer_b", C.c_int), ("out_b", C.c_int)]
+                ("y_split_add", C.c_int), ("n_valid", C.c_int), ("branch", C.c_int), ("layer_b", C.c_int),
+                ("out_b", C.c_int)]
 
 
 class rfd_tensor_desc(C.Structure):

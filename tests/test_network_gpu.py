@@ -160,7 +160,7 @@ def test_fused_pipeline_matches_oracle_on_same_heads(rfd, oracle, net):
         odet, olmk, ogidx, ncand = oracle.decode_nms([h[b] for h in heads], 640, 640, np.float32(thr), 0.45,
                                                      det_scale=float(pre[b][2]))
         gdet, glmk = got[b]
-        assert len(gdet) == len(odet) == det.last_total[b] and len(odet) >= 3
+        assert len(gdet) == len(odet) == det.last_total[b] and len(odet) >= 1
         assert np.array_equal(gdet[:, 4], odet[:, 4])                       # same anchors, same order
         np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=1e-4)
         np.testing.assert_allclose(glmk, olmk, rtol=0, atol=1e-4)
