@@ -271,6 +271,12 @@ RFD_API int rfd_debug_tensor_io(rfd_ctx *ctx, int tensor_id, int n, void *host, 
 RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
 /* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal */
 RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
+/* execution structure of the network pass: side streams for independent chains on/off; batch split into
+ * clamp(n / split_min_part, 1, split_max_parts) contiguous parts that run as independent chains on their own streams
+ * (split_max_parts <= 1 = never; at most 4); hipGraph replay of unsplit passes on/off.  Every structure gives
+ * bit-identical results (tests/test_concurrency_gpu.py). */
+RFD_API int rfd_debug_set_concurrency(rfd_ctx *ctx, int multi_stream, int split_min_part, int split_max_parts,
+                                      int use_graph);
 
 #ifdef __cplusplus
 }

@@ -580,6 +580,19 @@ int rfd_debug_set_conv_tile(rfd_ctx *c, int tile)
     c->net.force_tile = tile;
     return RFD_OK;
 }
+int rfd_debug_set_concurrency(rfd_ctx *c, int multi_stream, int split_min_part, int split_max_parts, int use_graph)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_TRY(c->ensure_network());
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    c->net.multi_stream = multi_stream != 0;
+    c->net.split_min_part = split_min_part;
+    c->net.split_max_parts = split_max_parts;
+    c->net.use_graph = use_graph != 0;
+    for (hipGraphExec_t &ge : c->net.graph_exec)
+        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+    return RFD_OK;
+}
 int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
 {
     RFD_CHECK_ARG(c, "ctx is null");

@@ -1070,13 +1070,14 @@ int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const fl
 //   dwconv3x3_kernel: depthwise 3x3 (stride 1 or 2, pad 1) + bias + ReLU, NHWC, 8 channels (16 B) per thread,
 //                     weights [9][C] bf16.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) first3x3_kernel(const bf16_t *__restrict__ x4, const bf16_t *__restrict__ w, // [8][3][3][4]
+// The 288 weights are wave-uniform and indexed by compile-time constants, so they are fetched with scalar loads
+// (s_load_dwordxN of bf16 pairs) straight into SGPRs -- no LDS table.  (An earlier version kept them as floats in LDS
+// and read them with broadcast ds_read_b128; on MI355X those reads returned wrong data in lanes 48..63 whenever a
+// conv workgroup of ANOTHER stream, streaming its tiles in with LDS-DMA, shared the CU -- see DESIGN.md, "concurrency".)
+__global__ void __launch_bounds__(256) first3x3_kernel(const bf16_t *__restrict__ x4, const uint32_t *__restrict__ w2, // [8][3][3][4] bf16 as pairs
                                                        const float *__restrict__ bias, bf16_t *__restrict__ y, int B,
                                                        int H, int W, int Ho, int Wo, int Cd)
 {
-    __shared__ float ws[8 * 36];
-    for (int i = threadIdx.x; i < 8 * 36; i += 256) ws[i] = bf16_bits_to_f32(w[i]);
-    __syncthreads();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)B * Ho * Wo) return;
     const int wo = (int)(i % Wo);
@@ -1097,8 +1098,8 @@ __global__ void __launch_bounds__(256) first3x3_kernel(const bf16_t *__restrict_
             const float r = bf16_bits_to_f32(p.x & 0xffffu), g = bf16_bits_to_f32(p.x >> 16), bl = bf16_bits_to_f32(p.y & 0xffffu);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float *wc = ws + c * 36 + (ky * 3 + kx) * 4;
-                acc[c] += r * wc[0] + g * wc[1] + bl * wc[2];
+                const uint32_t d0 = w2[c * 18 + (ky * 3 + kx) * 2], d1 = w2[c * 18 + (ky * 3 + kx) * 2 + 1];
+                acc[c] += r * bf16_bits_to_f32(d0 & 0xffffu) + g * bf16_bits_to_f32(d0 >> 16) + bl * bf16_bits_to_f32(d1 & 0xffffu);
             }
         }
     }
@@ -1114,8 +1115,8 @@ int launch_first3x3(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t
 {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)B * Ho * Wo;
-    hipLaunchKernelGGL(first3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x4, w, bias, y, B, H, W,
-                       Ho, Wo, Cd);
+    hipLaunchKernelGGL(first3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x4,
+                       reinterpret_cast<const uint32_t *>(w), bias, y, B, H, W, Ho, Wo, Cd);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }

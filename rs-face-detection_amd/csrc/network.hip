@@ -324,7 +324,14 @@ void Graph::plan()
             d.buffer = (int)buffer_bytes_per_image.size() - 1;
         }
     };
-    assign(input);
+    // batch-contiguous I/O tensors (written by preprocess / read by decode over the whole batch): exclusive buffers
+    auto assign_exclusive = [&](int t) {
+        buffer_bytes_per_image.push_back(tensors[t].bytes_per_image());
+        tensors[t].buffer = (int)buffer_bytes_per_image.size() - 1;
+        tensors[t].last = nops; // never released
+    };
+    assign_exclusive(input);
+    for (int l = 0; l < 3; ++l) assign_exclusive(heads[l]);
     for (int i = 0; i < nops; ++i) {
         for (size_t t = 0; t < tensors.size(); ++t) // release tensors dead before op i
             if (tensors[t].buffer >= 0 && tensors[t].last == i - 1 && tensors[t].last < nops)
@@ -389,11 +396,18 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     RFD_HIP(hipMalloc((void **)&d_b, (g.b_total + g.a_total) * sizeof(float))); // biases, then affines
     RFD_HIP(hipMemset(d_w, 0, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMemset(d_b, 0, (g.b_total + g.a_total) * sizeof(float)));
-    for (int i = 0; i < 2; ++i) {
-        RFD_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
-        RFD_HIP(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
-        RFD_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    for (int hh = 0; hh < kMaxParts; ++hh) {
+        for (int i = 0; i < 2; ++i) {
+            RFD_HIP(hipStreamCreateWithFlags(&side[hh][i], hipStreamNonBlocking));
+            RFD_HIP(hipEventCreateWithFlags(&ev_fork[hh][i], hipEventDisableTiming));
+            RFD_HIP(hipEventCreateWithFlags(&ev_join[hh][i], hipEventDisableTiming));
+        }
+        if (hh) {
+            RFD_HIP(hipStreamCreateWithFlags(&part_stream[hh], hipStreamNonBlocking));
+            RFD_HIP(hipEventCreateWithFlags(&ev_part_join[hh], hipEventDisableTiming));
+        }
     }
+    RFD_HIP(hipEventCreateWithFlags(&ev_part_fork, hipEventDisableTiming));
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
@@ -413,12 +427,19 @@ void Network::destroy()
     d_zero = nullptr;
     for (void *p : d_buffers)
         if (p) (void)hipFree(p);
-    for (int i = 0; i < 2; ++i) {
-        if (side[i]) (void)hipStreamDestroy(side[i]);
-        if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
-        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-        side[i] = nullptr; ev_fork[i] = ev_join[i] = nullptr;
+    for (int hh = 0; hh < kMaxParts; ++hh) {
+        for (int i = 0; i < 2; ++i) {
+            if (side[hh][i]) (void)hipStreamDestroy(side[hh][i]);
+            if (ev_fork[hh][i]) (void)hipEventDestroy(ev_fork[hh][i]);
+            if (ev_join[hh][i]) (void)hipEventDestroy(ev_join[hh][i]);
+            side[hh][i] = nullptr; ev_fork[hh][i] = ev_join[hh][i] = nullptr;
+        }
+        if (part_stream[hh]) (void)hipStreamDestroy(part_stream[hh]);
+        if (ev_part_join[hh]) (void)hipEventDestroy(ev_part_join[hh]);
+        part_stream[hh] = nullptr; ev_part_join[hh] = nullptr;
     }
+    if (ev_part_fork) (void)hipEventDestroy(ev_part_fork);
+    ev_part_fork = nullptr;
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (hipGraphExec_t ge : graph_exec)
         if (ge) (void)hipGraphExecDestroy(ge);
@@ -604,10 +625,10 @@ int Network::get_affine(int idx, float *scale, float *shift, hipStream_t s)
     return RFD_OK;
 }
 
-int Network::run(int B, hipStream_t s, int first_op, int last_op)
+int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off, int part)
 {
     if (!weights_ready) { set_error("network weights are not initialised (rfd_init_synthetic_weights / rfd_set_layer_weights)"); return RFD_ERR_STATE; }
-    if (B < 1 || B > max_batch) { set_error("batch %d exceeds max_batch_size %d", B, max_batch); return RFD_ERR_CAPACITY; }
+    if (B < 1 || batch_off + B > max_batch) { set_error("batch %d exceeds max_batch_size %d", batch_off + B, max_batch); return RFD_ERR_CAPACITY; }
     const int nops = (int)g.ops.size();
     if (profiling && (int)ev.size() < 2 * nops) {
         const size_t old = ev.size();
@@ -615,9 +636,9 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         for (size_t i = old; i < ev.size(); ++i) RFD_HIP(hipEventCreate(&ev[i]));
     }
     if (last_op < 0 || last_op >= nops) last_op = nops - 1;
-    prof_first = std::max(first_op, 0); prof_last = last_op;
+    if (part == 0) { prof_first = std::max(first_op, 0); prof_last = last_op; }
     hipStream_t main_stream = s;
-    const bool fork_ok = multi_stream && !profiling && first_op <= 0 && last_op == nops - 1 && side[0] && side[1];
+    const bool fork_ok = multi_stream && !profiling && first_op <= 0 && last_op == nops - 1 && side[part][0] && side[part][1];
     bool forked[2] = {false, false};
     for (int i = std::max(first_op, 0); i <= last_op; ++i) {
         const Op &o = g.ops[i];
@@ -627,65 +648,65 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
         if (fork_ok && o.branch > 0) {
             const int bidx = o.branch - 1;
             if (!forked[bidx]) { // everything this chain reads was enqueued on the main stream before this point
-                RFD_HIP(hipEventRecord(ev_fork[bidx], main_stream));
-                RFD_HIP(hipStreamWaitEvent(side[bidx], ev_fork[bidx], 0));
+                RFD_HIP(hipEventRecord(ev_fork[part][bidx], main_stream));
+                RFD_HIP(hipStreamWaitEvent(side[part][bidx], ev_fork[part][bidx], 0));
                 forked[bidx] = true;
             }
-            s = side[bidx];
+            s = side[part][bidx];
         }
         if (profiling) RFD_HIP(hipEventRecord(ev[2 * i], s));
         if (o.kind == OP_CONV0) {
-            RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off,
-                                 (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+            RFD_TRY(launch_conv0((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off,
+                                 (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s));
         } else if (o.kind == OP_FIRST) {
-            RFD_TRY(launch_first3x3((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out), B,
+            RFD_TRY(launch_first3x3((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out, batch_off), B,
                                     tin.H, tin.W, g.tensors[o.out].C, s));
         } else if (o.kind == OP_DW) {
-            RFD_TRY(launch_dwconv3x3((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out), B,
+            RFD_TRY(launch_dwconv3x3((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out, batch_off), B,
                                      tin.H, tin.W, tin.C, L.stride, s));
         } else if (o.kind == OP_STEM) {
-            RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
-                                d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out), B, tin.H, tin.W, s));
+            RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
+                                d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s));
         } else if (o.kind == OP_B2B) {
             const Layer &Lb = g.layers[o.layer_b];
             B2BParams bp;
             memset(&bp, 0, sizeof bp);
-            bp.x = (const bf16_t *)tensor_ptr(o.in);
+            bp.x = (const bf16_t *)tensor_ptr(o.in, batch_off);
             bp.w3 = d_w + L.w_off;
             bp.bias3 = d_b + L.b_off;
             if (o.layer2 >= 0) {
                 const Layer &L2 = g.layers[o.layer2];
-                bp.x2 = (const bf16_t *)tensor_ptr(o.in2);
+                bp.x2 = (const bf16_t *)tensor_ptr(o.in2, batch_off);
                 bp.bias3b = d_b + L2.b_off;
                 bp.Cin2 = L2.cin_d;
             }
-            bp.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
+            bp.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res, batch_off) : nullptr;
             bp.scale = d_b + g.b_total + L.a_off;
             bp.shift = d_b + g.b_total + L.a_off + L.cout_d;
-            bp.raw = (bf16_t *)tensor_ptr(o.out);
+            bp.raw = (bf16_t *)tensor_ptr(o.out, batch_off);
             bp.w1 = d_w + Lb.w_off;
             bp.bias1 = d_b + Lb.b_off;
-            bp.t1 = (bf16_t *)tensor_ptr(o.out_b);
+            bp.t1 = (bf16_t *)tensor_ptr(o.out_b, batch_off);
             bp.B = B; bp.H = tin.H; bp.W = tin.W; bp.Cin = L.cin_d;
             RFD_TRY(launch_conv_b2b_s1(bp, s));
         } else if (o.kind == OP_POOL) {
-            RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in), (bf16_t *)tensor_ptr(o.out),
+            RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in, batch_off), (bf16_t *)tensor_ptr(o.out, batch_off),
                                         d_b + g.b_total + L.a_off, d_b + g.b_total + L.a_off + L.cout_d, B, tin.H, tin.W,
                                         tin.C, s));
         } else {
             const int tout = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
             ConvParams p;
             memset(&p, 0, sizeof p);
-            p.x = (const bf16_t *)tensor_ptr(o.in);
+            p.x = (const bf16_t *)tensor_ptr(o.in, batch_off);
             p.w = d_w + L.w_off;
             p.bias = d_b + L.b_off;
             p.zero = d_zero;
             p.force_tile = force_tile;
-            p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res) : nullptr;
+            p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res, batch_off) : nullptr;
             if (o.layer2 >= 0) {
                 const Layer &L2 = g.layers[o.layer2];
                 const TensorDesc &t2 = g.tensors[o.in2];
-                p.x2 = (const bf16_t *)tensor_ptr(o.in2);
+                p.x2 = (const bf16_t *)tensor_ptr(o.in2, batch_off);
                 p.bias2 = d_b + L2.b_off;
                 p.H2 = t2.H; p.W2 = t2.W; p.Cin2 = L2.cin_d; p.stride2 = L2.stride;
             }
@@ -696,9 +717,9 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
             }
             p.scale2 = d_b + g.b_total + L.a_off;
             p.shift2 = d_b + g.b_total + L.a_off + L.cout_d;
-            p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out) : nullptr;
-            p.y2 = o.out2 >= 0 ? (bf16_t *)tensor_ptr(o.out2) : nullptr;
-            p.yf = o.outf >= 0 ? (float *)tensor_ptr(o.outf) : nullptr;
+            p.y = o.out >= 0 ? (bf16_t *)tensor_ptr(o.out, batch_off) : nullptr;
+            p.y2 = o.out2 >= 0 ? (bf16_t *)tensor_ptr(o.out2, batch_off) : nullptr;
+            p.yf = o.outf >= 0 ? (float *)tensor_ptr(o.outf, batch_off) : nullptr;
             p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin_d;
             p.Cout = L.cout_d + (o.layer_n2 >= 0 ? g.layers[o.layer_n2].cout_d : 0); // N-fused sibling: its rows follow
             p.n_valid = o.n_valid;
@@ -714,15 +735,39 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op)
     }
     for (int bidx = 0; bidx < 2; ++bidx)
         if (forked[bidx]) { // join
-            RFD_HIP(hipEventRecord(ev_join[bidx], side[bidx]));
-            RFD_HIP(hipStreamWaitEvent(main_stream, ev_join[bidx], 0));
+            RFD_HIP(hipEventRecord(ev_join[part][bidx], side[part][bidx]));
+            RFD_HIP(hipStreamWaitEvent(main_stream, ev_join[part][bidx], 0));
         }
+    return RFD_OK;
+}
+
+// Split passes are never captured into a hipGraph (run_graphed): replayed from a graph they measured slower than the
+// unsplit graph, and the nested fork/join topology (caller stream -> part stream -> side streams) makes
+// hipStreamEndCapture of this ROCm (7.0 runtime) recurse without end.
+int Network::run_split(int B, hipStream_t s)
+{
+    const int P = num_parts(B);
+    if (P <= 1) return run(B, s);
+    RFD_HIP(hipEventRecord(ev_part_fork, s));
+    int off = 0;
+    for (int p = 0; p < P; ++p) {
+        const int Bp = B / P + (p < B % P ? 1 : 0);
+        if (p == 0) {
+            RFD_TRY(run(Bp, s, 0, -1, 0, 0));
+        } else {
+            RFD_HIP(hipStreamWaitEvent(part_stream[p], ev_part_fork, 0));
+            RFD_TRY(run(Bp, part_stream[p], 0, -1, off, p));
+            RFD_HIP(hipEventRecord(ev_part_join[p], part_stream[p]));
+        }
+        off += Bp;
+    }
+    for (int p = 1; p < P; ++p) RFD_HIP(hipStreamWaitEvent(s, ev_part_join[p], 0));
     return RFD_OK;
 }
 
 int Network::run_graphed(int B, hipStream_t s)
 {
-    if (!use_graph || profiling || B < 1 || B > max_batch) return run(B, s);
+    if (!use_graph || profiling || B < 1 || B > max_batch || num_parts(B) > 1) return run_split(B, s);
     if ((int)graph_exec.size() <= max_batch) { graph_exec.assign(max_batch + 1, nullptr); warmed.assign(max_batch + 1, 0); }
     if (graph_exec[B]) {
         RFD_HIP(hipGraphLaunch(graph_exec[B], s));
@@ -730,23 +775,23 @@ int Network::run_graphed(int B, hipStream_t s)
     }
     if (!warmed[B]) { // first call for this batch size runs eagerly (hipFuncSetAttribute etc. are not capturable)
         warmed[B] = 1;
-        return run(B, s);
+        return run_split(B, s);
     }
     hipGraph_t graph = nullptr;
     RFD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    const int st = run(B, s);
+    const int st = run_split(B, s);
     const hipError_t e = hipStreamEndCapture(s, &graph);
     if (st != RFD_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         use_graph = false; // capture unsupported here: stay eager
-        return st != RFD_OK ? st : run(B, s);
+        return st != RFD_OK ? st : run_split(B, s);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess || !exec) {
         use_graph = false;
-        return run(B, s);
+        return run_split(B, s);
     }
     graph_exec[B] = exec;
     RFD_HIP(hipGraphLaunch(exec, s));

@@ -91,7 +91,7 @@ API_SYMBOLS = [
     "rfd_set_layer_weights", "rfd_get_layer_affine", "rfd_set_layer_affine", "rfd_detect_batch",
     "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
-    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_selection_config_default",
+    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_debug_set_concurrency", "rfd_selection_config_default",
     "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
 ]
 
@@ -151,6 +151,7 @@ def load_library(path=None):
     L.rfd_debug_tensor_io.argtypes = [vp, ci, ci, vp, ci]
     L.rfd_debug_run_ops.argtypes = [vp, ci, ci, ci]
     L.rfd_debug_set_conv_tile.argtypes = [vp, ci]
+    L.rfd_debug_set_concurrency.argtypes = [vp, ci, ci, ci, ci]
     L.rfd_save_weights.argtypes = [vp, C.c_char_p]
     L.rfd_load_weights.argtypes = [vp, C.c_char_p]
     L.rfd_selection_config_default.argtypes = [vp]
@@ -454,6 +455,10 @@ class RetinaFaceDetection:
 
     def debug_set_conv_tile(self, tile):
         _check(self._L.rfd_debug_set_conv_tile(self._ctx, tile))
+
+    def debug_set_concurrency(self, multi_stream=True, split_min_part=8, split_max_parts=2, use_graph=True):
+        _check(self._L.rfd_debug_set_concurrency(self._ctx, int(multi_stream), int(split_min_part), int(split_max_parts),
+                                                 int(use_graph)))
 
     def debug_run(self, n, first_op, last_op):
         _check(self._L.rfd_debug_run_ops(self._ctx, n, first_op, last_op))
