@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 runs of bench.py (rocpd .db output of ROCm 7) into the files committed under profiles/.
+
+  rocpd_summary.py stats  <kernel_trace.db>            -> kernel_stats.csv on stdout-like file + network busy time
+  rocpd_summary.py pmc    <fetch.db> <write.db>        -> HBM bytes per forward pass of the network conv kernels
+
+"pass" = one detect call = one preprocess_kernel launch.  Network class = conv_igemm / conv3x3_kx / conv_b2b_s1 /
+stem kernels.  With the batch split the two parts' kernels overlap, so next to the per-kernel averages the summary
+reports the UNION of the class's busy intervals per pass -- the figure bench.py's roofline uses (network wall time).
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide reads / LDS-DMA at half their bytes -> x2;
+WRITE_SIZE is exact; both in KiB."""
+import json
+import sqlite3
+import statistics
+import sys
+
+NET = ("conv_igemm_kernel", "conv3x3_kx_kernel", "conv_b2b_s1_kernel", "stem_kernel")
+
+
+def is_net(name):
+    return any(t in name for t in NET)
+
+
+def short(name):
+    return name.replace("void ", "").split("(")[0]
+
+
+def stats(path, out_csv, out_json):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        a = agg.setdefault(short(n), [0, 0.0])
+        a[0] += 1
+        a[1] += (e - s) / 1e3
+    total = sum(v[1] for v in agg.values())
+    with open(out_csv, "w") as f:
+        f.write("kernel,calls,total_us,avg_us,percent\n")
+        for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k, c, t, t / c, 100 * t / total))
+    # per pass: union of the network class's busy intervals, and the sum of its kernel durations
+    passes, cur = [], None
+    for n, s, e in rows:
+        if "preprocess_kernel" in n:
+            cur = {"iv": [], "n": 0}
+            passes.append(cur)
+        elif cur is not None and is_net(n):
+            cur["iv"].append((s, e))
+            cur["n"] += 1
+    busy, summed, counts = [], [], []
+    for p in passes:
+        if not p["iv"]:
+            continue
+        iv = sorted(p["iv"])
+        u, (cs, ce) = 0, iv[0]
+        for s, e in iv[1:]:
+            if s > ce:
+                u += ce - cs
+                cs, ce = s, e
+            else:
+                ce = max(ce, e)
+        u += ce - cs
+        busy.append(u / 1e6)
+        summed.append(sum(e - s for s, e in iv) / 1e6)
+        counts.append(p["n"])
+    mode = statistics.mode(counts)
+    sel = [i for i, c in enumerate(counts) if c == mode]
+    out = {"passes": len(busy), "launches_per_pass_mode": mode,
+           "network_busy_ms_per_pass_median": statistics.median(busy[i] for i in sel),
+           "network_kernel_time_sum_ms_per_pass_median": statistics.median(summed[i] for i in sel),
+           "note": "busy = union of the start..end intervals of the network kernels of one pass (two parts overlap)"}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps(out))
+
+
+def pmc(fetch_db, write_db, out_json):
+    def load(path, counter):
+        db = sqlite3.connect(path)
+        per, calls = {}, {}
+        for n, v in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            k = short(n)
+            per[k] = per.get(k, 0.0) + v
+            calls[k] = calls.get(k, 0) + 1
+        return per, calls
+    fetch, calls = load(fetch_db, "FETCH_SIZE")
+    write, _ = load(write_db, "WRITE_SIZE")
+    passes = max(calls.get("rfd::preprocess_kernel", 0), 1)
+    rows, nf, nw = {}, 0.0, 0.0
+    for k in sorted(set(fetch) | set(write)):
+        f = 2.0 * fetch.get(k, 0.0) * 1024 / passes
+        w = write.get(k, 0.0) * 1024 / passes
+        rows[k] = {"calls_per_pass": round(calls.get(k, 0) / passes, 2), "fetch_bytes_per_pass": f, "write_bytes_per_pass": w}
+        if is_net(k):
+            nf += f
+            nw += w
+    out = {"passes": passes, "conv_igemm_hbm_bytes_per_pass": nf + nw, "network_fetch_bytes_per_pass": nf,
+           "network_write_bytes_per_pass": nw, "class": list(NET),
+           "correction": "FETCH_SIZE x2 (gfx950 wide-read tally), WRITE_SIZE x1, KiB -> bytes", "kernels": rows}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
