@@ -250,6 +250,34 @@ RFD_API int rfd_select_faces(rfd_ctx *ctx, const rfd_dets *dets, const int *img_
 RFD_API int rfd_detect_select_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, const rfd_selection_config *cfg,
                                     int is_enroll, float *out_box, float *out_kps, int32_t *found);
 
+/* ---- FaceAlignment: FaceAlignment::call, src/pipeline/module/face_alignment.rs:27-141 --
+ *      the step after selection in FacePipeline::extract (pipeline.rs:210-216).  For each frame the selected face is
+ *      mapped onto the out_w x out_h template: 4-DOF similarity from its five key points to `standard_landmarks`
+ *      (replaces estimate_affine_partial_2d(LMEDS) :48-60 by the closed-form least-squares similarity it refines to
+ *      -- a documented divergence) + cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) :112-120 restated in integer
+ *      arithmetic; degenerate key points take the reference's crop + resize branch :62-110.
+ *      Defaults = FaceAlignmentConfig::new (config.rs:44-56): 112 x 112 and the ArcFace template.
+ *      status[i]: 0 aligned, 1 crop + resize fallback, -1 no key points (the reference's call returns Err),
+ *      -2 no face selected, -3 fallback ROI outside the frame (the reference's Mat::roi returns Err); crops with a
+ *      negative status are zero-filled.  out_crops: [n][out_h][out_w][3] u8 BGR, host. ---- */
+typedef struct rfd_alignment_config {
+    int32_t out_w, out_h;            /* 112, 112 */
+    float standard_landmarks[10];    /* x0,y0 ... x4,y4 */
+    int32_t reserved[4];
+} rfd_alignment_config;
+RFD_API void rfd_alignment_config_default(rfd_alignment_config *cfg);
+/* Stage-level: frames (host), selected boxes [n][5], key points [n][10] and flags found [n] as returned by
+ * rfd_select_faces / rfd_detect_select_batch. */
+RFD_API int rfd_align_faces(rfd_ctx *ctx, const rfd_image *imgs, int n, const float *boxes, const float *kps,
+                            const int32_t *found, const rfd_alignment_config *cfg, uint8_t *out_crops,
+                            int32_t *status);
+/* Fused: detect + select + align n frames; the frames cross PCIe once, detections never leave HBM, 16 floats and one
+ * crop per frame come back.  = FacePipeline::extract lines 198-216 (pipeline.rs). */
+RFD_API int rfd_detect_select_align_batch(rfd_ctx *ctx, const rfd_image *imgs, int n,
+                                          const rfd_selection_config *sel_cfg, int is_enroll,
+                                          const rfd_alignment_config *align_cfg, float *out_box, float *out_kps,
+                                          int32_t *found, uint8_t *out_crops, int32_t *status);
+
 /* ---- introspection ---- */
 RFD_API int rfd_get_stats(rfd_ctx *ctx, rfd_stats *stats);
 RFD_API int rfd_get_config(const rfd_ctx *ctx, rfd_config *cfg);

@@ -60,6 +60,14 @@ def lib():
         L.rfd_oracle_face_selection.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                 C.c_float, C.c_float, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]
         L.rfd_oracle_face_selection.restype = C.c_int
+        _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        L.rfd_oracle_estimate_similarity.argtypes = [_f32p, _f32p, C.c_int, _f64p]
+        L.rfd_oracle_estimate_similarity.restype = C.c_int
+        L.rfd_oracle_warp_affine_u8c3.argtypes = [_u8p, C.c_int, C.c_int, C.c_ssize_t, _f64p, _u8p, C.c_int, C.c_int]
+        L.rfd_oracle_warp_affine_u8c3.restype = None
+        L.rfd_oracle_face_alignment.argtypes = [_u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_void_p, _f32p, C.c_int,
+                                                C.c_int, _u8p]
+        L.rfd_oracle_face_alignment.restype = C.c_int
         _lib = L
     return _lib
 
@@ -190,3 +198,39 @@ def face_selection(boxes, kps, img_h, img_w, is_enroll=False, margin_center_left
     if not r:
         return None, None
     return ob, (ok.reshape(5, 2) if found.value else None)
+
+
+# FaceAlignmentConfig::new (config.rs:44-56)
+STANDARD_LANDMARKS = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366], [41.5493, 92.3655],
+                               [70.7299, 92.2041]], np.float32)
+
+
+def estimate_similarity(src, dst):
+    """closed-form 4-DOF least-squares similarity src -> dst; returns the 2x3 f64 matrix or None (degenerate)."""
+    s = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    M = np.zeros(6, np.float64)
+    ok = lib().rfd_oracle_estimate_similarity(s, d, s.shape[0], M)
+    return M.reshape(2, 3) if ok else None
+
+
+def warp_affine(src, M, out_h, out_w):
+    """cv::warpAffine(src, M, (out_w, out_h), INTER_LINEAR, BORDER_CONSTANT, 0) restated."""
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((out_h, out_w, 3), np.uint8)
+    lib().rfd_oracle_warp_affine_u8c3(src, src.shape[0], src.shape[1], src.strides[0],
+                                      np.ascontiguousarray(M, np.float64).reshape(6), dst, out_h, out_w)
+    return dst
+
+
+def face_alignment(src, box, kps, image_size=(112, 112), standard_landmarks=STANDARD_LANDMARKS):
+    """FaceAlignment::call (face_alignment.rs:27-141) -> (crop [h,w,3] u8, status 0 warp / 1 fallback / -1 ROI error)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    b = None if box is None else np.ascontiguousarray(box, np.float32)
+    k = None if kps is None else np.ascontiguousarray(kps, np.float32).reshape(10)
+    dst = np.zeros((image_size[1], image_size[0], 3), np.uint8)
+    st = lib().rfd_oracle_face_alignment(src, src.shape[0], src.shape[1], src.strides[0],
+                                         None if b is None else b.ctypes.data, None if k is None else k.ctypes.data,
+                                         np.ascontiguousarray(standard_landmarks, np.float32).reshape(10),
+                                         image_size[0], image_size[1], dst)
+    return dst, st

@@ -542,3 +542,119 @@ RFD_API int rfd_oracle_face_selection(const float *boxes, const float *kps, int 
     }
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * FaceAlignment::call -- src/pipeline/module/face_alignment.rs:27-141, with the 112x112
+ * template of FaceAlignmentConfig::new (src/pipeline/face_pipeline/config.rs:46-52).
+ *
+ * Third-party arithmetic, "parity unpinned" (no OpenCV in this image, the reference's test is commented out,
+ * face_alignment.rs:148-240):
+ *  - estimate_affine_partial_2d(landmarks -> template, LMEDS, 3.0, 2000, 0.99, 10) (:48-60) is OpenCV calib3d:
+ *    random 2-point samples, least-median selection, then 10 Levenberg-Marquardt iterations on the inliers.
+ *    The refined model minimises the squared reprojection error of a 4-DOF similarity [a -b tx; b a ty], a
+ *    LINEAR least-squares problem; with all five landmarks inliers its unique minimum is the closed form below.
+ *    DOCUMENTED DIVERGENCE: the closed form over all five points replaces sampling + refinement (no outlier
+ *    rejection); a degenerate input (all landmarks coincide) takes the reference's empty-matrix branch (:62).
+ *  - warp_affine(INTER_LINEAR, BORDER_CONSTANT, 0) (:112-120) restates cv::warpAffine (imgwarp.cpp): the 2x3
+ *    matrix is inverted in f64, coordinates are 10-bit fixed point (AB_BITS) reduced to 5 fractional bits
+ *    (INTER_BITS), bilinear weights are the 15-bit table products, out-of-image taps read 0, result
+ *    (sum + 2^14) >> 15.
+ * ------------------------------------------------------------------------------------------ */
+RFD_API int rfd_oracle_estimate_similarity(const float *src, const float *dst, int n, double M[6])
+{
+    double msx = 0, msy = 0, mdx = 0, mdy = 0;
+    for (int i = 0; i < n; ++i) {
+        msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
+        mdx += (double)dst[2 * i]; mdy += (double)dst[2 * i + 1];
+    }
+    msx /= n; msy /= n; mdx /= n; mdy /= n;
+    double sxx = 0, sa = 0, sb = 0;
+    for (int i = 0; i < n; ++i) {
+        const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
+        const double xd = (double)dst[2 * i] - mdx, yd = (double)dst[2 * i + 1] - mdy;
+        sxx += xs * xs + ys * ys;
+        sa += xs * xd + ys * yd;
+        sb += xs * yd - ys * xd;
+    }
+    if (!(sxx > 0.0)) return 0; /* degenerate: the reference's `transformation_matrix.empty()` branch */
+    const double a = sa / sxx, b = sb / sxx;
+    M[0] = a; M[1] = -b; M[2] = mdx - (a * msx - b * msy);
+    M[3] = b; M[4] = a;  M[5] = mdy - (b * msx + a * msy);
+    return 1;
+}
+
+static int cv_round_sat(double v) /* cv::saturate_cast<int>(double) = cvRound: nearest, ties to even */
+{
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int)lrint(v);
+}
+
+RFD_API void rfd_oracle_warp_affine_u8c3(const unsigned char *src, int h, int w, ptrdiff_t stride, const double Mfwd[6],
+                                         unsigned char *dst, int dh, int dw)
+{
+    double M[6];
+    memcpy(M, Mfwd, sizeof M);
+    { /* invert (no WARP_INVERSE_MAP) */
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1; M[5] = b2;
+    }
+    const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, INTER_BITS = 5, TAB = 1 << INTER_BITS;
+    const int round_delta = AB_SCALE / TAB / 2;
+    for (int y = 0; y < dh; ++y) {
+        const int X0 = cv_round_sat((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = cv_round_sat((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < dw; ++x) {
+            const int adelta = cv_round_sat(M[0] * x * AB_SCALE), bdelta = cv_round_sat(M[3] * x * AB_SCALE);
+            const int X = (X0 + adelta) >> (AB_BITS - INTER_BITS), Y = (Y0 + bdelta) >> (AB_BITS - INTER_BITS);
+            int sx = X >> INTER_BITS, sy = Y >> INTER_BITS; /* saturate_cast<short> */
+            sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+            sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+            const int fx = X & (TAB - 1), fy = Y & (TAB - 1);
+            int wt[4] = {(TAB - fy) * (TAB - fx) * 32, (TAB - fy) * fx * 32, fy * (TAB - fx) * 32, fy * fx * 32};
+            if (fx == 0 && fy == 0) { wt[0] = 32767; wt[3] = 1; } /* saturate_cast<short>(32768) + the table's sum fix-up */
+            unsigned char *d = dst + ((size_t)y * dw + x) * 3;
+            for (int c = 0; c < 3; ++c) {
+                int acc = 0;
+                for (int t = 0; t < 4; ++t) {
+                    const int px = sx + (t & 1), py = sy + (t >> 1);
+                    const int v = (px >= 0 && px < w && py >= 0 && py < h) ? src[(ptrdiff_t)py * stride + px * 3 + c] : 0;
+                    acc += v * wt[t];
+                }
+                d[c] = (unsigned char)((acc + (1 << 14)) >> 15);
+            }
+        }
+    }
+}
+
+/* returns 0: aligned by the similarity warp; 1: the crop + resize fallback (:62-110) was taken; -1: the fallback's
+ * Rect leaves the image (Mat::roi error, :91-94).  box = selected detection or NULL (:64-71). */
+RFD_API int rfd_oracle_face_alignment(const unsigned char *src, int h, int w, ptrdiff_t stride, const float *box,
+                                      const float *kps, const float *std_lmk, int out_w, int out_h, unsigned char *dst)
+{
+    double M[6];
+    if (kps && rfd_oracle_estimate_similarity(kps, std_lmk, 5, M)) {
+        rfd_oracle_warp_affine_u8c3(src, h, w, stride, M, dst, out_h, out_w);
+        return 0;
+    }
+    float det[4];
+    if (!box) { /* :65-69 */
+        det[0] = (float)w * 0.0625f; det[1] = (float)h * 0.0625f;
+        det[2] = (float)w - det[0]; det[3] = (float)h - det[1];
+    } else {
+        memcpy(det, box, sizeof det);
+    }
+    const float margin = 44.0f;
+    const float bb0 = fmaxf(det[0] - margin / 2.0f, 0.0f), bb1 = fmaxf(det[1] - margin / 2.0f, 0.0f);
+    const float bb2 = fmaxf(det[2] + margin / 2.0f, (float)w); /* `max`, as written (:77) */
+    const float bb3 = fmaxf(det[1] + margin / 2.0f, (float)h); /* det[1], as written (:78) */
+    const int x0 = (int)bb0, y0 = (int)bb1, x1 = (int)bb2, y1 = (int)bb3;
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (rw <= 0 || rh <= 0 || x0 + rw > w || y0 + rh > h) return -1;
+    rfd_oracle_resize_linear_u8c3(src + (ptrdiff_t)y0 * stride + x0 * 3, rh, rw, stride, dst, out_h, out_w, (ptrdiff_t)out_w * 3);
+    return 1;
+}

@@ -112,6 +112,7 @@ struct rfd_ctx {
     DevBuf out_boxes, out_lmk, out_count, out_total, out_gidx;
     DevBuf scratch[12];
     DevBuf sel_dims, sel_out;
+    DevBuf align_faces, align_out, align_status;
     // pinned host ring for per-call descriptors, so enqueueing never blocks on the previous call
     static constexpr int kRing = 4;
     PreImage *pin_imgs[kRing] = {};
@@ -416,6 +417,7 @@ void rfd_destroy(rfd_ctx *c)
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->scratch) b.release();
     c->sel_dims.release(); c->sel_out.release();
+    c->align_faces.release(); c->align_out.release(); c->align_status.release();
     for (int i = 0; i < 10; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < rfd_ctx::kRing; ++i) {
@@ -897,6 +899,74 @@ int rfd_detect_select_batch(rfd_ctx *c, const rfd_image *imgs, int n, const rfd_
     std::vector<int> hh(n), ww(n);
     for (int i = 0; i < n; ++i) { hh[i] = imgs[i].height; ww[i] = imgs[i].width; }
     return select_impl(c, dev.boxes, dev.landmarks, dev.count, hh.data(), ww.data(), n, cfg, is_enroll, out_box, out_kps, found);
+}
+
+void rfd_alignment_config_default(rfd_alignment_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->out_w = 112; cfg->out_h = 112; // config.rs:46
+    static const float tmpl[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f, 41.5493f, 92.3655f, 70.7299f, 92.2041f}; // :47-52
+    memcpy(cfg->standard_landmarks, tmpl, sizeof tmpl);
+}
+
+// alignment of the frames whose descriptors sit in c->imgs (the last staged batch); selection results are device
+// arrays; crops and status are copied to the host pointers
+static int align_impl(rfd_ctx *c, int n, const float *d_box, const float *d_kps, const int *d_found,
+                      const rfd_alignment_config *cfg, uint8_t *out_crops, int32_t *status)
+{
+    rfd_alignment_config def;
+    rfd_alignment_config_default(&def);
+    if (!cfg) cfg = &def;
+    if (cfg->out_w < 1 || cfg->out_h < 1 || cfg->out_w > 4096 || cfg->out_h > 4096) {
+        set_error("alignment output size %dx%d out of range", cfg->out_w, cfg->out_h);
+        return RFD_ERR_INVALID_ARG;
+    }
+    const size_t crop = (size_t)cfg->out_w * cfg->out_h * 3;
+    RFD_TRY(c->align_faces.reserve((size_t)n * sizeof(AlignFace)));
+    RFD_TRY(c->align_out.reserve((size_t)n * crop));
+    RFD_TRY(c->align_status.reserve((size_t)n * sizeof(int)));
+    AlignParams ap;
+    memset(&ap, 0, sizeof ap);
+    ap.imgs = (const PreImage *)c->imgs.p;
+    ap.box = d_box; ap.kps = d_kps; ap.found = d_found;
+    memcpy(ap.std_lmk, cfg->standard_landmarks, sizeof ap.std_lmk);
+    ap.out_w = cfg->out_w; ap.out_h = cfg->out_h; ap.n = n;
+    ap.faces = (AlignFace *)c->align_faces.p;
+    ap.status = (int *)c->align_status.p;
+    ap.out = (uint8_t *)c->align_out.p;
+    RFD_TRY(launch_face_align(ap, c->stream));
+    RFD_HIP(hipMemcpyAsync(out_crops, ap.out, (size_t)n * crop, hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(status, ap.status, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+
+int rfd_align_faces(rfd_ctx *c, const rfd_image *imgs, int n, const float *boxes, const float *kps, const int32_t *found,
+                    const rfd_alignment_config *cfg, uint8_t *out_crops, int32_t *status)
+{
+    RFD_CHECK_ARG(c && boxes && kps && found && out_crops && status, "null argument");
+    RFD_TRY(check_images(c, imgs, n));
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    std::vector<float> scales;
+    RFD_TRY(stage_frames(c, imgs, n, false, scales));
+    RFD_TRY(c->sel_out.reserve((size_t)n * 16 * sizeof(float)));
+    float *o = (float *)c->sel_out.p;
+    RFD_HIP(hipMemcpyAsync(o, boxes, (size_t)n * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipMemcpyAsync(o + (size_t)n * 5, kps, (size_t)n * 10 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipMemcpyAsync(o + (size_t)n * 15, found, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    return align_impl(c, n, o, o + (size_t)n * 5, (const int *)(o + (size_t)n * 15), cfg, out_crops, status);
+}
+
+int rfd_detect_select_align_batch(rfd_ctx *c, const rfd_image *imgs, int n, const rfd_selection_config *sel_cfg, int is_enroll,
+                                  const rfd_alignment_config *align_cfg, float *out_box, float *out_kps, int32_t *found,
+                                  uint8_t *out_crops, int32_t *status)
+{
+    RFD_CHECK_ARG(c && out_crops && status, "null argument");
+    // the staged frames and their descriptors (c->staging / c->imgs) stay valid until the next call on this context
+    RFD_TRY(rfd_detect_select_batch(c, imgs, n, sel_cfg, is_enroll, out_box, out_kps, found));
+    const float *o = (const float *)c->sel_out.p;
+    return align_impl(c, n, o, o + (size_t)n * 5, (const int *)(o + (size_t)n * 15), align_cfg, out_crops, status);
 }
 
 int rfd_nms_sorted(rfd_ctx *c, int32_t *keep, int *num_out, const float *boxes, int boxes_num, int boxes_dim,

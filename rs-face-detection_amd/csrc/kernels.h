@@ -79,6 +79,29 @@ struct SelectParams {
 };
 int launch_face_select(const SelectParams &p, hipStream_t s);
 
+// FaceAlignment::call on the device (face_alignment.rs:27-141): 5-point similarity to the template + cv::warpAffine
+// (INTER_LINEAR, BORDER_CONSTANT 0) of the source frame, or the reference's crop + resize fallback
+struct AlignFace {      // per face, filled by the set-up kernel
+    double M[6];        // inverse map (dst -> src), as cv::warpAffine computes it
+    double scale_x, scale_y; // fallback resize
+    int mode;           // 0 warp, 1 crop + resize, < 0 nothing written (status)
+    int x0, y0, rw, rh; // fallback ROI
+    int area_fast;
+};
+struct AlignParams {
+    const PreImage *imgs; // [n] frames of the batch (device descriptors)
+    const float *box;     // [n][5] selected detection
+    const float *kps;     // [n][10] its key points
+    const int *found;     // [n] selection flags: bit 0 box, bit 1 key points
+    float std_lmk[10];    // template (config.rs:46-52)
+    int out_w, out_h, n;
+    AlignFace *faces;     // [n] scratch
+    int *status;          // [n]: 0 aligned, 1 fallback crop, -1 no key points (the reference's call errors), -2 no face,
+                          //      -3 fallback ROI outside the frame (Mat::roi error)
+    uint8_t *out;         // [n][out_h][out_w][3] u8 BGR
+};
+int launch_face_align(const AlignParams &p, hipStream_t s);
+
 // ---------------------------------------------------------------- convolution engine (kernels_conv.hip)
 // Activations: NHWC bf16.  Weights: [Cout][KH][KW][Cin] bf16 (K contiguous).  f32 accumulate on MFMA.
 struct ConvParams {

@@ -20,6 +20,41 @@ __device__ __forceinline__ int coef11(float v)
     return max(-32768, min(32767, r));
 }
 
+// one destination pixel of cv::resize(INTER_LINEAR) on CV_8UC3 (see the header): v = B,G,R
+__device__ __forceinline__ void resize_linear_px(const uint8_t *src, long long stride, int h, int w, double scale_x,
+                                                 double scale_y, int area_fast, int x, int y, int v[3])
+{
+    if (area_fast) {
+        const uint8_t *s0 = src + (long long)(2 * y) * stride + 2 * x * 3;
+        const uint8_t *s1 = s0 + stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (s0[c] + s0[c + 3] + s1[c] + s1[c + 3] + 2) >> 2;
+        return;
+    }
+    float fx = (float)(((double)x + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.0f; sx = 0; }
+    if (sx >= w - 1) { fx = 0.0f; sx = w - 1; }
+    const int a0 = coef11((1.0f - fx) * 2048.0f), a1 = coef11(fx * 2048.0f);
+    const int sx1 = min(sx + 1, w - 1);
+
+    float fy = (float)(((double)y + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = coef11((1.0f - fy) * 2048.0f), b1 = coef11(fy * 2048.0f);
+    const int sy0 = min(max(sy, 0), h - 1), sy1 = min(max(sy + 1, 0), h - 1);
+    const uint8_t *S0 = src + (long long)sy0 * stride;
+    const uint8_t *S1 = src + (long long)sy1 * stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int r0 = S0[sx * 3 + c] * a0 + S0[sx1 * 3 + c] * a1;
+        const int r1 = S1[sx * 3 + c] * a0 + S1[sx1 * 3 + c] * a1;
+        v[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v[c] = min(255, max(0, v[c]));
+    }
+}
+
 __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
 {
     const int b = blockIdx.z;
@@ -29,37 +64,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
     const PreImage im = p.imgs[b];
 
     int v[3] = {0, 0, 0}; // B,G,R of the canvas pixel; outside the pasted region the canvas is 0
-    if (x < im.new_w && y < im.new_h) {
-        if (im.area_fast) {
-            const uint8_t *s0 = im.src + (long long)(2 * y) * im.stride + 2 * x * 3;
-            const uint8_t *s1 = s0 + im.stride;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = (s0[c] + s0[c + 3] + s1[c] + s1[c + 3] + 2) >> 2;
-        } else {
-            float fx = (float)(((double)x + 0.5) * im.scale_x - 0.5);
-            int sx = (int)floorf(fx);
-            fx -= (float)sx;
-            if (sx < 0) { fx = 0.0f; sx = 0; }
-            if (sx >= im.w - 1) { fx = 0.0f; sx = im.w - 1; }
-            const int a0 = coef11((1.0f - fx) * 2048.0f), a1 = coef11(fx * 2048.0f);
-            const int sx1 = min(sx + 1, im.w - 1);
-
-            float fy = (float)(((double)y + 0.5) * im.scale_y - 0.5);
-            const int sy = (int)floorf(fy);
-            fy -= (float)sy;
-            const int b0 = coef11((1.0f - fy) * 2048.0f), b1 = coef11(fy * 2048.0f);
-            const int sy0 = min(max(sy, 0), im.h - 1), sy1 = min(max(sy + 1, 0), im.h - 1);
-            const uint8_t *S0 = im.src + (long long)sy0 * im.stride;
-            const uint8_t *S1 = im.src + (long long)sy1 * im.stride;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int r0 = S0[sx * 3 + c] * a0 + S0[sx1 * 3 + c] * a1;
-                const int r1 = S1[sx * 3 + c] * a0 + S1[sx1 * 3 + c] * a1;
-                v[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                v[c] = min(255, max(0, v[c]));
-            }
-        }
-    }
+    if (x < im.new_w && y < im.new_h) resize_linear_px(im.src, im.stride, im.h, im.w, im.scale_x, im.scale_y, im.area_fast, x, y, v);
     const size_t pix = ((size_t)b * p.net_h + y) * p.net_w + x;
     if (p.out_nhwc4) {
         // u8 -> bf16 is exact (8 significant bits); channel order R,G,B,0 (face_detection.rs:226 [2-i])
@@ -119,6 +124,133 @@ int launch_tensor_to_nhwc4(const float *tensor, bf16_t *out, int n, int H, int W
     const size_t plane = (size_t)H * W, total = plane * n;
     hipLaunchKernelGGL(tensor_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        tensor, out, plane, total);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FaceAlignment::call (face_alignment.rs:27-141).  Set-up: one thread per face estimates the 4-DOF similarity from
+// the five key points to the template in f64 (closed-form least squares -- the minimum the reference's LMEDS + LM
+// refinement converges to when all five points are inliers; documented divergence) and inverts it as
+// cv::warpAffine does; a degenerate point set takes the reference's crop + resize branch (:62-110, quirks kept).
+// Warp: one thread per output pixel, cv::warpAffine's fixed-point coordinates (10 -> 5 fractional bits) and 15-bit
+// bilinear weights, out-of-image taps = 0.  Integer-exact against the oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_sat(double v)
+{
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return __double2int_rn(v);
+}
+
+__global__ void align_setup_kernel(AlignParams p)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.n) return;
+    AlignFace f;
+    memset(&f, 0, sizeof f);
+    const int found = p.found[b];
+    const PreImage im = p.imgs[b];
+    if (!(found & 1)) {
+        f.mode = -2;
+    } else if (!(found & 2)) {
+        f.mode = -1; // landmarks = None: estimate_affine_partial_2d rejects the empty point set (:48)
+    } else {
+        const float *src = p.kps + (size_t)b * 10;
+        double msx = 0, msy = 0, mdx = 0, mdy = 0;
+        for (int i = 0; i < 5; ++i) {
+            msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
+            mdx += (double)p.std_lmk[2 * i]; mdy += (double)p.std_lmk[2 * i + 1];
+        }
+        msx /= 5; msy /= 5; mdx /= 5; mdy /= 5;
+        double sxx = 0, sa = 0, sb = 0;
+        for (int i = 0; i < 5; ++i) {
+            const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
+            const double xd = (double)p.std_lmk[2 * i] - mdx, yd = (double)p.std_lmk[2 * i + 1] - mdy;
+            sxx += xs * xs + ys * ys;
+            sa += xs * xd + ys * yd;
+            sb += xs * yd - ys * xd;
+        }
+        if (sxx > 0.0) {
+            const double a = sa / sxx, bb = sb / sxx;
+            double M[6] = {a, -bb, mdx - (a * msx - bb * msy), bb, a, mdy - (bb * msx + a * msy)};
+            double D = M[0] * M[4] - M[1] * M[3];
+            D = D != 0 ? 1. / D : 0;
+            const double A11 = M[4] * D, A22 = M[0] * D;
+            M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+            const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+            M[2] = b1; M[5] = b2;
+            for (int i = 0; i < 6; ++i) f.M[i] = M[i];
+            f.mode = 0;
+        } else { // empty transformation (:62): crop around the box and resize
+            const float *det = p.box + (size_t)b * 5;
+            const float margin = 44.0f;
+            const float bb0 = fmaxf(det[0] - margin / 2.0f, 0.0f), bb1 = fmaxf(det[1] - margin / 2.0f, 0.0f);
+            const float bb2 = fmaxf(det[2] + margin / 2.0f, (float)im.w); // `max`, as written (:77)
+            const float bb3 = fmaxf(det[1] + margin / 2.0f, (float)im.h); // det[1], as written (:78)
+            f.x0 = (int)bb0; f.y0 = (int)bb1;
+            f.rw = (int)bb2 - f.x0; f.rh = (int)bb3 - f.y0;
+            if (f.rw <= 0 || f.rh <= 0 || f.x0 + f.rw > im.w || f.y0 + f.rh > im.h) {
+                f.mode = -3;
+            } else {
+                f.mode = 1;
+                f.scale_x = 1.0 / ((double)p.out_w / f.rw);
+                f.scale_y = 1.0 / ((double)p.out_h / f.rh);
+                const int ix = cv_round_sat(f.scale_x), iy = cv_round_sat(f.scale_y);
+                f.area_fast = fabs(f.scale_x - ix) < 2.220446049250313e-16 && fabs(f.scale_y - iy) < 2.220446049250313e-16 &&
+                              ix == 2 && iy == 2;
+            }
+        }
+    }
+    p.faces[b] = f;
+    p.status[b] = f.mode;
+}
+
+__global__ void __launch_bounds__(256) align_warp_kernel(AlignParams p)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.out_w * p.out_h) return;
+    const int y = i / p.out_w, x = i - y * p.out_w;
+    const AlignFace &f = p.faces[b];
+    uint8_t *d = p.out + ((size_t)b * p.out_h * p.out_w + i) * 3;
+    if (f.mode < 0) { d[0] = d[1] = d[2] = 0; return; }
+    const PreImage im = p.imgs[b];
+    int v[3];
+    if (f.mode == 1) {
+        resize_linear_px(im.src + (long long)f.y0 * im.stride + f.x0 * 3, im.stride, f.rh, f.rw, f.scale_x, f.scale_y,
+                         f.area_fast, x, y, v);
+    } else {
+        constexpr int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, INTER_BITS = 5, TAB = 1 << INTER_BITS;
+        constexpr int round_delta = AB_SCALE / TAB / 2;
+        const int X0 = cv_round_sat((f.M[1] * y + f.M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = cv_round_sat((f.M[4] * y + f.M[5]) * AB_SCALE) + round_delta;
+        const int adelta = cv_round_sat(f.M[0] * x * AB_SCALE), bdelta = cv_round_sat(f.M[3] * x * AB_SCALE);
+        const int X = (X0 + adelta) >> (AB_BITS - INTER_BITS), Y = (Y0 + bdelta) >> (AB_BITS - INTER_BITS);
+        const int sx = max(-32768, min(32767, X >> INTER_BITS)), sy = max(-32768, min(32767, Y >> INTER_BITS));
+        const int fx = X & (TAB - 1), fy = Y & (TAB - 1);
+        int wt[4] = {(TAB - fy) * (TAB - fx) * 32, (TAB - fy) * fx * 32, fy * (TAB - fx) * 32, fy * fx * 32};
+        if (fx == 0 && fy == 0) { wt[0] = 32767; wt[3] = 1; }
+        int acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int px = sx + (t & 1), py = sy + (t >> 1);
+            if (px >= 0 && px < im.w && py >= 0 && py < im.h) {
+                const uint8_t *s = im.src + (long long)py * im.stride + px * 3;
+                acc[0] += s[0] * wt[t]; acc[1] += s[1] * wt[t]; acc[2] += s[2] * wt[t];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (acc[c] + (1 << 14)) >> 15;
+    }
+    d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
+}
+
+int launch_face_align(const AlignParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(align_setup_kernel, dim3(ceil_div(p.n, 64)), dim3(64), 0, s, p);
+    RFD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(align_warp_kernel, dim3(ceil_div(p.out_w * p.out_h, 256), p.n), dim3(256), 0, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }

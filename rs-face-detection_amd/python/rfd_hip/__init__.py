@@ -76,6 +76,11 @@ class rfd_op_desc(C.Structure):
                 ("out_b", C.c_int)]
 
 
+class rfd_alignment_config(C.Structure):
+    _fields_ = [("out_w", C.c_int32), ("out_h", C.c_int32), ("standard_landmarks", C.c_float * 10),
+                ("reserved", C.c_int32 * 4)]
+
+
 class rfd_tensor_desc(C.Structure):
     _fields_ = [("channels", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("is_f32", C.c_int), ("buffer", C.c_int), ("is_input", C.c_int),
@@ -93,6 +98,7 @@ API_SYMBOLS = [
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
     "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_debug_set_concurrency", "rfd_selection_config_default",
     "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
+    "rfd_alignment_config_default", "rfd_align_faces", "rfd_detect_select_align_batch",
 ]
 
 _lib = None
@@ -158,6 +164,10 @@ def load_library(path=None):
     L.rfd_selection_config_default.restype = None
     L.rfd_select_faces.argtypes = [vp, C.POINTER(rfd_dets), vp, vp, ci, vp, ci, vp, vp, vp]
     L.rfd_detect_select_batch.argtypes = [vp, C.POINTER(rfd_image), ci, vp, ci, vp, vp, vp]
+    L.rfd_alignment_config_default.argtypes = [C.POINTER(rfd_alignment_config)]
+    L.rfd_alignment_config_default.restype = None
+    L.rfd_align_faces.argtypes = [vp, C.POINTER(rfd_image), ci, vp, vp, vp, vp, vp, vp]
+    L.rfd_detect_select_align_batch.argtypes = [vp, C.POINTER(rfd_image), ci, vp, ci, vp, vp, vp, vp, vp, vp]
     if path is None:
         _lib = L
     return L
@@ -388,6 +398,51 @@ class RetinaFaceDetection:
         _check(self._L.rfd_detect_select_batch(self._ctx, arr, n, C.addressof(c), 1 if is_enroll else 0,
                                                ob.ctypes.data, ok.ctypes.data, fd.ctypes.data))
         return self._sel_out(ob, ok, fd)
+
+    # ---- the stage after selection: FaceAlignment::call (face_alignment.rs:27-141) ----
+    def _align_cfg(self, image_size=None, standard_landmarks=None):
+        c = rfd_alignment_config()
+        self._L.rfd_alignment_config_default(C.byref(c))  # FaceAlignmentConfig::new, config.rs:44-56
+        if image_size is not None:
+            c.out_w, c.out_h = int(image_size[0]), int(image_size[1])
+        if standard_landmarks is not None:
+            for i, v in enumerate(np.asarray(standard_landmarks, np.float32).reshape(10)):
+                c.standard_landmarks[i] = v
+        return c
+
+    def align_faces(self, frames, selected, image_size=None, standard_landmarks=None):
+        """frames: list of HxWx3 u8 BGR; selected: list of (box [5] or None, kps [5,2] or None) as select_faces /
+        detect_select return them.  -> crops [n, out_h, out_w, 3] u8, status [n] (see rfd.h)."""
+        arr, keep = self._images(frames)
+        n = len(frames)
+        ob, ok, fd = np.zeros((n, 5), np.float32), np.zeros((n, 10), np.float32), np.zeros(n, np.int32)
+        for i, (b, k) in enumerate(selected):
+            if b is not None:
+                ob[i] = b
+                fd[i] |= 1
+            if k is not None:
+                ok[i] = np.asarray(k, np.float32).reshape(10)
+                fd[i] |= 2
+        c = self._align_cfg(image_size, standard_landmarks)
+        crops = np.zeros((n, c.out_h, c.out_w, 3), np.uint8)
+        status = np.zeros(n, np.int32)
+        _check(self._L.rfd_align_faces(self._ctx, arr, n, ob.ctypes.data, ok.ctypes.data, fd.ctypes.data, C.addressof(c),
+                                       crops.ctypes.data, status.ctypes.data))
+        return crops, status
+
+    def detect_select_align(self, frames, is_enroll=False, sel_cfg=None, image_size=None, standard_landmarks=None):
+        """FacePipeline::extract lines 198-216: detect, select, align -> (selected list, crops, status)."""
+        arr, keep = self._images(frames)
+        n = len(frames)
+        ob, ok, fd = np.zeros((n, 5), np.float32), np.zeros((n, 10), np.float32), np.zeros(n, np.int32)
+        sc = self._sel_cfg(sel_cfg)
+        c = self._align_cfg(image_size, standard_landmarks)
+        crops = np.zeros((n, c.out_h, c.out_w, 3), np.uint8)
+        status = np.zeros(n, np.int32)
+        _check(self._L.rfd_detect_select_align_batch(self._ctx, arr, n, C.addressof(sc), 1 if is_enroll else 0,
+                                                     C.addressof(c), ob.ctypes.data, ok.ctypes.data, fd.ctypes.data,
+                                                     crops.ctypes.data, status.ctypes.data))
+        return self._sel_out(ob, ok, fd), crops, status
 
     # ---- stage-level entry points ----
     def preprocess(self, frames):

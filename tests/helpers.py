@@ -76,3 +76,18 @@ def bf16_bits_to_f32(u16):
 def f32_to_bf16_bits(x):
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def make_face_kps(seed, h, w, scale_range=(0.6, 3.5), max_rot_deg=35.0):
+    """Five key points = the 112x112 ArcFace template under a random similarity (scale, rotation, shift) somewhere in
+    an h x w frame, plus a little per-point jitter; returns (kps [5,2] f32, box [5] f32)."""
+    rng = np.random.default_rng(seed)
+    tmpl = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366], [41.5493, 92.3655], [70.7299, 92.2041]])
+    s = rng.uniform(*scale_range)
+    th = np.deg2rad(rng.uniform(-max_rot_deg, max_rot_deg))
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    c = np.array([rng.uniform(0.1 * w, 0.9 * w), rng.uniform(0.1 * h, 0.9 * h)])
+    kps = (tmpl - 56.0) @ R.T * s + c + rng.normal(0, 0.6, size=(5, 2))
+    lo, hi = kps.min(0) - 25 * s, kps.max(0) + 25 * s
+    box = np.array([lo[0], lo[1], hi[0], hi[1], 0.9], np.float32)
+    return kps.astype(np.float32), box

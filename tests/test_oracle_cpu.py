@@ -193,3 +193,53 @@ def test_face_selection_semantics(oracle):
     d = np.array([[401, 201, 521, 341, .9], [400, 200, 522, 342, .8]], np.float32)
     ob, ok = oracle.face_selection(d, k[:2], 720, 1280)
     assert ob.tolist() == d[1].tolist() and np.array_equal(ok, k[0])
+
+
+def test_alignment_similarity_and_warp(oracle):
+    """FaceAlignment restatement (face_alignment.rs:27-141): closed-form similarity + cv::warpAffine fixed point."""
+    O = oracle
+    # exact recovery of a known similarity
+    th = np.deg2rad(-17.0)
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    src = (O.STANDARD_LANDMARKS.astype(np.float64) @ R.T) * 1.7 + np.array([211.0, 95.0])
+    M = O.estimate_similarity(src, O.STANDARD_LANDMARKS)
+    assert np.abs(src.astype(np.float32) @ M[:, :2].T + M[:, 2] - O.STANDARD_LANDMARKS).max() < 1e-4
+    assert abs(M[0, 0] - M[1, 1]) < 1e-12 and abs(M[0, 1] + M[1, 0]) < 1e-12          # 4 degrees of freedom
+    assert O.estimate_similarity(np.tile([[5.0, 6.0]], (5, 1)), O.STANDARD_LANDMARKS) is None  # degenerate
+    img = helpers.make_image(3, 200, 260, n_blobs=4)
+    # identity map copies pixels; integer shifts too (weights 32767 + 1 at exact positions)
+    eye = np.array([[1, 0, 0], [0, 1, 0]], np.float64)
+    assert np.array_equal(O.warp_affine(img, eye, 112, 112), img[:112, :112])
+    sh = np.array([[1, 0, -7], [0, 1, -9]], np.float64)
+    assert np.array_equal(O.warp_affine(img, sh, 112, 112), img[9:121, 7:119])
+    # fractional shift: within half a level of float bilinear
+    T = np.array([[1, 0, -5.5], [0, 1, -3.25]], np.float64)
+    w = O.warp_affine(img, T, 64, 64).astype(np.float64)
+    f = img.astype(np.float64)
+    e = 0.5 * (0.75 * f[3:67, 5:69] + 0.25 * f[4:68, 5:69]) + 0.5 * (0.75 * f[3:67, 6:70] + 0.25 * f[4:68, 6:70])
+    assert np.abs(w - e).max() <= 0.5 + 1e-9
+    # outside the frame: BORDER_CONSTANT 0, and the half-covered edge column blends with 0
+    out = O.warp_affine(img, np.array([[1, 0, 40.5], [0, 1, 0]], np.float64), 8, 48)
+    assert not out[:, :40].any()
+    assert np.array_equal(out[:, 40], (img[:8, 0].astype(np.int32) * 16384 + 16384) >> 15)
+
+
+def test_alignment_branches_and_golden(oracle):
+    O = oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "align_112.npz"))
+    crop, st = O.face_alignment(g["img"], g["box"], g["kps"])
+    assert st == int(g["status"]) == 0 and np.array_equal(crop, g["crop"])
+    assert np.allclose(O.estimate_similarity(g["kps"], O.STANDARD_LANDMARKS), g["M"], rtol=0, atol=1e-12)
+    img = g["img"]                                           # 240 x 320
+    same = np.tile([[100.0, 100.0]], (5, 1))
+    # empty-transformation branch (:62-110) with the reference's quirks: x1 = max(x2 + 22, W), y1 = max(y1 + 22, H)
+    crop, st = O.face_alignment(img, [60, 50, 200, 150, 0.9], same)
+    assert st == 1
+    assert np.array_equal(crop, O.resize_linear(img[28:240, 38:320], 112, 112))
+    # no box: the 1/16 margins (:65-69)
+    big = helpers.make_image(5, 400, 480, n_blobs=4)
+    crop2, st2 = O.face_alignment(big, None, same)
+    assert st2 == 1 and np.array_equal(crop2, O.resize_linear(big[3:400, 8:480], 112, 112))
+    assert O.face_alignment(img, None, same)[1] == -1         # W - W/16 + 22 > W for frames narrower than 352
+    # x2 + 22 > W: the Rect leaves the image -> Mat::roi error
+    assert O.face_alignment(img, [60, 50, 310, 150, 0.9], same)[1] == -1
