@@ -120,6 +120,8 @@ def main():
 
     stream = torch.cuda.current_stream()
     det.set_stream(stream.cuda_stream)  # detector, RCCL and torch share one stream order
+    if os.environ.get("RFD_BENCH_TILE"):  # experiment knob: forced conv tile configuration (rfd_debug_set_conv_tile)
+        det.debug_set_conv_tile(int(os.environ["RFD_BENCH_TILE"]))
     if os.environ.get("RFD_BENCH_CONC"):  # experiment knob: "multi_stream,split_min_part,split_max_parts,use_graph"
         ms, sp, mp_, gr = (int(v) for v in os.environ["RFD_BENCH_CONC"].split(","))
         det.debug_set_concurrency(bool(ms), sp, mp_, bool(gr))

@@ -129,6 +129,7 @@ struct ConvParams {
     int res_up2;          // residual is half resolution: read at (ho/2, wo/2) (FPN nearest 2x)
     int res_post;         // add the residual AFTER the ReLU (FPN: relu(lateral) + upsampled)
     int force_tile;       // 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tile (tuning / tests)
+    int co_running;       // another chain of the same pass runs concurrently (batch split): affects the tile heuristic
     int head_softmax;     // heads: channels [0,4) are cls logits -> 2-class softmax pairs (a, A+a)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);

@@ -763,7 +763,17 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
     if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);
     // (with BN = 64 the merged-kx kernel measured 7 % slower than the generic 128x64 tile at 3 workgroups / CU)
-    if (p.Cout % 128 == 0 && p.force_tile != 4) {
+    // Per-layer tile choice for a chain that has the GPU to itself (unsplit passes, B < 16; tools/tile_sweep.py): the
+    // 128x64 tile (3 workgroups per CU, twice the grid) wins by 5-28 % where the 128x128 grid cannot give every CU a
+    // workgroup, and by 5-11 % on the 1x1 layers whose FLOPs per byte of activation traffic are far below the machine
+    // balance (more loads in flight per CU).  With a second chain co-running (batch split) the other chain already
+    // fills those gaps and the same choice measured 2.5 % SLOWER end to end, so it is not applied there.
+    const long long n128 = (long long)ceil_div(M, 128) * (p.Cout / 128);
+    const double act_bytes = 2.0 * ((double)(p.KH * p.KW * p.Cin + p.Cin2) / (p.stride * p.stride) +
+                                    (double)p.Cout * (1 + (p.res ? 1 : 0) + (p.y && p.y2 ? 1 : 0)));
+    const double flop_per_byte = 2.0 * (p.KH * p.KW * p.Cin + p.Cin2) * p.Cout / act_bytes;
+    const bool prefer_small = p.force_tile == 0 && !p.co_running && (n128 <= 256 || (p.KH == 1 && flop_per_byte < 110.0));
+    if (p.Cout % 128 == 0 && p.force_tile != 4 && !prefer_small) {
         // The 8-wave 256x128 tile with a 3-slot ring (1 workgroup per CU) measured 5-13 % SLOWER than two
         // co-resident 128x128 workgroups on every layer of this network (profiles/): opt-in only.
         (void)M; (void)nk;

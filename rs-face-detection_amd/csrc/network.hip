@@ -702,6 +702,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             p.bias = d_b + L.b_off;
             p.zero = d_zero;
             p.force_tile = force_tile;
+            p.co_running = co_running;
             p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res, batch_off) : nullptr;
             if (o.layer2 >= 0) {
                 const Layer &L2 = g.layers[o.layer2];
@@ -747,8 +748,10 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
 int Network::run_split(int B, hipStream_t s)
 {
     const int P = num_parts(B);
+    co_running = 0;
     if (P <= 1) return run(B, s);
     RFD_HIP(hipEventRecord(ev_part_fork, s));
+    co_running = 1;
     int off = 0;
     for (int p = 0; p < P; ++p) {
         const int Bp = B / P + (p < B % P ? 1 : 0);
@@ -761,6 +764,7 @@ int Network::run_split(int B, hipStream_t s)
         }
         off += Bp;
     }
+    co_running = 0;
     for (int p = 1; p < P; ++p) RFD_HIP(hipStreamWaitEvent(s, ev_part_join[p], 0));
     return RFD_OK;
 }
