@@ -250,6 +250,20 @@ RFD_API int rfd_select_faces(rfd_ctx *ctx, const rfd_dets *dets, const int *img_
 RFD_API int rfd_detect_select_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, const rfd_selection_config *cfg,
                                     int is_enroll, float *out_box, float *out_kps, int32_t *found);
 
+/* ---- pipelined host entry (host decode + H2D staging, utils.rs:8-52 is the producer) ----
+ *      rfd_detect_batch is synchronous, so the PCIe copy of a batch cannot overlap the compute of the previous one.
+ *      rfd_submit_batch enqueues H2D (own copy stream) + the whole hot path + D2H of the detections and returns;
+ *      rfd_collect_batch waits for the OLDEST submitted batch and fills `out` exactly as rfd_detect_batch would.
+ *      Up to 2 batches may be in flight (a third submit returns RFD_ERR_STATE).  The frames must stay valid and
+ *      unchanged until their batch has been collected.  For the copy to be a true asynchronous DMA the frames should
+ *      live in page-locked memory: rfd_host_alloc / rfd_host_free hand it out (decode straight into it); pageable
+ *      frames work but are copied synchronously by the runtime.  Not to be mixed with the other detect calls while a
+ *      batch is in flight. ---- */
+RFD_API int rfd_host_alloc(size_t bytes, void **ptr);
+RFD_API int rfd_host_free(void *ptr);
+RFD_API int rfd_submit_batch(rfd_ctx *ctx, const rfd_image *imgs, int n);
+RFD_API int rfd_collect_batch(rfd_ctx *ctx, rfd_dets *out, int *n_out);
+
 /* ---- FaceAlignment: FaceAlignment::call, src/pipeline/module/face_alignment.rs:27-141 --
  *      the step after selection in FacePipeline::extract (pipeline.rs:210-216).  For each frame the selected face is
  *      mapped onto the out_w x out_h template: 4-DOF similarity from its five key points to `standard_landmarks`

@@ -119,6 +119,20 @@ struct rfd_ctx {
     float *pin_scales[kRing] = {};
     hipEvent_t pin_done[kRing] = {};
     int pin_next = 0;
+    // pipelined host entry (rfd_submit_batch / rfd_collect_batch): two slots, H2D on its own stream
+    struct PipeSlot {
+        DevBuf frames, imgs, scale, ob, ol, oc, ot;
+        PreImage *pin_imgs = nullptr;
+        float *pin_scale = nullptr;
+        float *h_ob = nullptr, *h_ol = nullptr;
+        int *h_oc = nullptr, *h_ot = nullptr;
+        hipEvent_t h2d = nullptr, done = nullptr;
+        int n = 0;
+    };
+    static constexpr int kPipe = 2;
+    PipeSlot pipe[kPipe];
+    hipStream_t copy_stream = nullptr;
+    int pipe_head = 0, pipe_tail = 0, pipe_inflight = 0;
     rfd_stats stats;
     float conv_ms = 0.f;
     double conv_flops = 0.0;
@@ -224,7 +238,7 @@ void fill_decode_params(const rfd_ctx *c, DecodeParams &p)
 
 // decode -> sort -> NMS on device-resident heads; outputs to device slabs `o*`.
 int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, float *olmk, int *ocount,
-                 int *ototal, int *ogidx)
+                 int *ototal, int *ogidx, const float *det_scale = nullptr)
 {
     RFD_HIP(hipMemsetAsync(c->count.p, 0, n * sizeof(int), c->stream));
     RFD_TRY(launch_decode(dp, n, nchw, c->stream));
@@ -238,7 +252,7 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
     np.sorted_boxes = (const float4 *)c->sorted_boxes.p;
     np.rows = (const float *)c->rows.p;
     np.count = (const int *)c->count.p;
-    np.det_scale = (const float *)c->det_scale.p;
+    np.det_scale = det_scale ? det_scale : (const float *)c->det_scale.p;
     np.presorted_n = -1;
     np.total_anchors = c->total_anchors;
     np.max_det = c->cfg.max_det;
@@ -425,6 +439,16 @@ void rfd_destroy(rfd_ctx *c)
         if (c->pin_scales[i]) (void)hipHostFree(c->pin_scales[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
     }
+    for (rfd_ctx::PipeSlot &ps : c->pipe) {
+        DevBuf *pb[] = {&ps.frames, &ps.imgs, &ps.scale, &ps.ob, &ps.ol, &ps.oc, &ps.ot};
+        for (DevBuf *b : pb) b->release();
+        void *hp[] = {ps.pin_imgs, ps.pin_scale, ps.h_ob, ps.h_ol, ps.h_oc, ps.h_ot};
+        for (void *h : hp)
+            if (h) (void)hipHostFree(h);
+        if (ps.h2d) (void)hipEventDestroy(ps.h2d);
+        if (ps.done) (void)hipEventDestroy(ps.done);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -742,6 +766,117 @@ int rfd_sync(rfd_ctx *c)
 {
     RFD_CHECK_ARG(c, "ctx is null");
     RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+
+// ---- pipelined host entry ----
+int rfd_host_alloc(size_t bytes, void **ptr)
+{
+    RFD_CHECK_ARG(ptr && bytes > 0, "bad argument");
+    RFD_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return RFD_OK;
+}
+int rfd_host_free(void *ptr)
+{
+    if (ptr) RFD_HIP(hipHostFree(ptr));
+    return RFD_OK;
+}
+
+int rfd_submit_batch(rfd_ctx *c, const rfd_image *imgs, int n)
+{
+    RFD_CHECK_ARG(c != nullptr, "ctx is null");
+    RFD_TRY(check_images(c, imgs, n));
+    if (c->pipe_inflight >= rfd_ctx::kPipe) {
+        set_error("%d batches are already in flight: call rfd_collect_batch first", c->pipe_inflight);
+        return RFD_ERR_STATE;
+    }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    const size_t B = (size_t)c->cfg.max_batch_size, MD = (size_t)c->cfg.max_det;
+    rfd_ctx::PipeSlot &ps = c->pipe[c->pipe_head];
+    if (!c->copy_stream) RFD_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!ps.done) { // first use of this slot
+        RFD_HIP(hipEventCreateWithFlags(&ps.h2d, hipEventDisableTiming));
+        RFD_HIP(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming));
+        RFD_HIP(hipHostMalloc((void **)&ps.pin_imgs, B * sizeof(PreImage), hipHostMallocDefault));
+        RFD_HIP(hipHostMalloc((void **)&ps.pin_scale, B * sizeof(float), hipHostMallocDefault));
+        RFD_HIP(hipHostMalloc((void **)&ps.h_ob, B * MD * 5 * sizeof(float), hipHostMallocDefault));
+        RFD_HIP(hipHostMalloc((void **)&ps.h_ol, B * MD * 10 * sizeof(float), hipHostMallocDefault));
+        RFD_HIP(hipHostMalloc((void **)&ps.h_oc, B * sizeof(int), hipHostMallocDefault));
+        RFD_HIP(hipHostMalloc((void **)&ps.h_ot, B * sizeof(int), hipHostMallocDefault));
+        RFD_TRY(ps.imgs.reserve(B * sizeof(PreImage)));
+        RFD_TRY(ps.scale.reserve(B * sizeof(float)));
+        RFD_TRY(ps.ob.reserve(B * MD * 5 * sizeof(float)));
+        RFD_TRY(ps.ol.reserve(B * MD * 10 * sizeof(float)));
+        RFD_TRY(ps.oc.reserve(B * sizeof(int)));
+        RFD_TRY(ps.ot.reserve(B * sizeof(int)));
+    }
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)imgs[i].height * imgs[i].width * 3;
+    if (total > ps.frames.cap) { // growing the frame buffer frees the old one: nothing of this slot is in flight (it was collected)
+        RFD_TRY(ps.frames.reserve(total + total / 4));
+    }
+    // copy stream: frames + descriptors of THIS batch while the main stream still computes the previous one
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        letterbox(imgs[i].height, imgs[i].width, c->cfg.image_w, c->cfg.image_h, &ps.pin_imgs[i], &ps.pin_scale[i]);
+        if (ps.pin_imgs[i].new_w <= 0 || ps.pin_imgs[i].new_h <= 0) {
+            set_error("invalid argument: frame %d (%dx%d) letterboxes to an empty image", i, imgs[i].width, imgs[i].height);
+            return RFD_ERR_INVALID_ARG;
+        }
+        uint8_t *dst = (uint8_t *)ps.frames.p + off;
+        const size_t row = (size_t)imgs[i].width * 3;
+        RFD_HIP(hipMemcpy2DAsync(dst, row, imgs[i].data, (size_t)imgs[i].stride, row, imgs[i].height, hipMemcpyHostToDevice,
+                                 c->copy_stream));
+        ps.pin_imgs[i].src = dst;
+        ps.pin_imgs[i].stride = (long long)row;
+        off += row * imgs[i].height;
+    }
+    RFD_HIP(hipMemcpyAsync(ps.imgs.p, ps.pin_imgs, n * sizeof(PreImage), hipMemcpyHostToDevice, c->copy_stream));
+    RFD_HIP(hipMemcpyAsync(ps.scale.p, ps.pin_scale, n * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    RFD_HIP(hipEventRecord(ps.h2d, c->copy_stream));
+    // main stream: the whole hot path of this batch, behind the previous batch
+    RFD_HIP(hipStreamWaitEvent(c->stream, ps.h2d, 0));
+    PreParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.imgs = (const PreImage *)ps.imgs.p;
+    pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
+    pp.out_nhwc4 = (bf16_t *)c->net.tensor_ptr(c->net.g.input);
+    RFD_TRY(launch_preprocess(pp, n, c->stream));
+    RFD_TRY(c->net.run_graphed(n, c->stream));
+    DecodeParams dp;
+    fill_decode_params(c, dp);
+    for (int l = 0; l < kNumLevels; ++l) dp.cls[l] = (const float *)c->net.tensor_ptr(c->net.g.heads[l]);
+    RFD_TRY(post_network(c, dp, false, n, (float *)ps.ob.p, (float *)ps.ol.p, (int *)ps.oc.p, (int *)ps.ot.p, nullptr,
+                         (const float *)ps.scale.p));
+    RFD_HIP(hipMemcpyAsync(ps.h_ob, ps.ob.p, n * MD * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(ps.h_ol, ps.ol.p, n * MD * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(ps.h_oc, ps.oc.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipMemcpyAsync(ps.h_ot, ps.ot.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RFD_HIP(hipEventRecord(ps.done, c->stream));
+    ps.n = n;
+    c->pipe_head = (c->pipe_head + 1) % rfd_ctx::kPipe;
+    ++c->pipe_inflight;
+    return RFD_OK;
+}
+
+int rfd_collect_batch(rfd_ctx *c, rfd_dets *out, int *n_out)
+{
+    RFD_CHECK_ARG(c && out && out->boxes && out->landmarks && out->count, "null argument");
+    if (c->pipe_inflight <= 0) { set_error("no batch in flight"); return RFD_ERR_STATE; }
+    rfd_ctx::PipeSlot &ps = c->pipe[c->pipe_tail];
+    RFD_HIP(hipEventSynchronize(ps.done));
+    const size_t MD = (size_t)c->cfg.max_det;
+    for (int i = 0; i < ps.n; ++i) {
+        const int k = ps.h_oc[i];
+        memcpy(out->boxes + (size_t)i * MD * 5, ps.h_ob + (size_t)i * MD * 5, (size_t)k * 5 * sizeof(float));
+        memcpy(out->landmarks + (size_t)i * MD * 10, ps.h_ol + (size_t)i * MD * 10, (size_t)k * 10 * sizeof(float));
+        out->count[i] = k;
+        if (out->total) out->total[i] = ps.h_ot[i];
+    }
+    if (n_out) *n_out = ps.n;
+    c->pipe_tail = (c->pipe_tail + 1) % rfd_ctx::kPipe;
+    --c->pipe_inflight;
     return RFD_OK;
 }
 

@@ -99,6 +99,7 @@ API_SYMBOLS = [
     "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_debug_set_concurrency", "rfd_selection_config_default",
     "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
     "rfd_alignment_config_default", "rfd_align_faces", "rfd_detect_select_align_batch",
+    "rfd_host_alloc", "rfd_host_free", "rfd_submit_batch", "rfd_collect_batch",
 ]
 
 _lib = None
@@ -164,6 +165,10 @@ def load_library(path=None):
     L.rfd_selection_config_default.restype = None
     L.rfd_select_faces.argtypes = [vp, C.POINTER(rfd_dets), vp, vp, ci, vp, ci, vp, vp, vp]
     L.rfd_detect_select_batch.argtypes = [vp, C.POINTER(rfd_image), ci, vp, ci, vp, vp, vp]
+    L.rfd_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.rfd_host_free.argtypes = [vp]
+    L.rfd_submit_batch.argtypes = [vp, C.POINTER(rfd_image), ci]
+    L.rfd_collect_batch.argtypes = [vp, C.POINTER(rfd_dets), C.POINTER(ci)]
     L.rfd_alignment_config_default.argtypes = [C.POINTER(rfd_alignment_config)]
     L.rfd_alignment_config_default.restype = None
     L.rfd_align_faces.argtypes = [vp, C.POINTER(rfd_image), ci, vp, vp, vp, vp, vp, vp]
@@ -260,6 +265,9 @@ class RetinaFaceDetection:
         self.max_det = cfg.max_det
 
     def close(self):
+        for p in getattr(self, "_pinned", []):
+            self._L.rfd_host_free(p)
+        self._pinned = []
         if getattr(self, "_ctx", None):
             self._L.rfd_destroy(self._ctx)
             self._ctx = None
@@ -336,6 +344,31 @@ class RetinaFaceDetection:
         _check(self._L.rfd_detect_batch(self._ctx, arr, len(frames), C.byref(d)))
         self.last_total = total
         return self._split(boxes, lmk, count)
+
+    # ---- pipelined host entry: the PCIe copy of batch i+1 overlaps the compute of batch i ----
+    def host_frames(self, n, h, w):
+        """n frames of h x w x 3 u8 in page-locked memory (rfd_host_alloc): decode into it, then submit()."""
+        p = C.c_void_p()
+        _check(self._L.rfd_host_alloc(n * h * w * 3, C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * (n * h * w * 3)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(n, h, w, 3)
+
+    def submit(self, frames):
+        arr, keep = self._images(frames)
+        self._inflight = getattr(self, "_inflight", [])
+        _check(self._L.rfd_submit_batch(self._ctx, arr, len(frames)))
+        self._inflight.append((len(frames), keep))  # the frames must outlive the batch
+
+    def collect(self):
+        n, _ = self._inflight[0] if getattr(self, "_inflight", None) else (self.cfg.max_batch_size, None)
+        d, boxes, lmk, count, total = self._alloc_dets(n)
+        got = C.c_int(0)
+        _check(self._L.rfd_collect_batch(self._ctx, C.byref(d), C.byref(got)))
+        self._inflight.pop(0)
+        self.last_total = total
+        return self._split(boxes[:got.value], lmk[:got.value], count[:got.value])
 
     def call(self, image, is_debug=None):
         """RetinaFaceDetection::call (face_detection.rs:496): -> (det [K,5], kps [K,5,2])."""

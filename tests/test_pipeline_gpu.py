@@ -1,0 +1,64 @@
+"""rfd_submit_batch / rfd_collect_batch: two batches in flight, H2D on its own stream.
+Results must equal the synchronous rfd_detect_batch on the same frames, in submission order."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pipelined_equals_synchronous(rfd, pinned):
+    n = 4
+    det = rfd.RetinaFaceDetection(max_batch_size=n, max_det=512, confidence_threshold=0.3, backbone=rfd.BACKBONE_MNET025)
+    det.init_synthetic_weights(1234)
+    batches = []
+    for b in range(5):
+        frames = [helpers.make_image(300 + 10 * b + i, 360 + 40 * ((b + i) % 3), 480 + 32 * (i % 2), n_blobs=5)
+                  for i in range(n if b != 3 else 2)]          # a ragged batch in the middle
+        batches.append(frames)
+    want = [det.call_batch(f) for f in batches]
+    assert sum(len(d) for w in want for d, _ in w) > 0
+    if pinned:   # same frames, living in page-locked memory handed out by the library
+        pin = []
+        for frames in batches:
+            pf = []
+            for f in frames:
+                buf = det.host_frames(1, f.shape[0], f.shape[1])[0]
+                buf[...] = f
+                pf.append(buf)
+            pin.append(pf)
+        batches = pin
+    got = []
+    det.submit(batches[0])
+    for b in range(1, len(batches)):
+        det.submit(batches[b])          # two in flight
+        got.append(det.collect())
+    got.append(det.collect())
+    for g, w in zip(got, want):
+        assert _same(g, w)
+    # the synchronous entry still works afterwards
+    assert _same(det.call_batch(batches[1]), want[1])
+    det.close()
+
+
+def test_pipeline_state_errors(rfd):
+    det = rfd.RetinaFaceDetection(max_batch_size=2, max_det=64, backbone=rfd.BACKBONE_MNET025)
+    det.init_synthetic_weights(1)
+    f = [helpers.make_image(1, 200, 300, n_blobs=2)]
+    with pytest.raises(rfd.RfdError) as e:
+        det.collect()                   # nothing in flight
+    assert e.value.status == rfd.RFD_ERR_STATE
+    det.submit(f)
+    det.submit(f)
+    with pytest.raises(rfd.RfdError) as e:
+        det.submit(f)                   # a third batch
+    assert e.value.status == rfd.RFD_ERR_STATE
+    a, b = det.collect(), det.collect()
+    assert _same(a, b)
+    det.close()

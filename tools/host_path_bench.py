@@ -27,3 +27,28 @@ for name, hw in (("640x640", (640, 640)), ("1920x1080", (1080, 1920))):
     t = float(np.median(ts))
     print("%-10s source frames, B=%d, host->host: %.2f ms/batch = %.0f img/s  (device: h2d %.2f pre %.2f net %.2f post %.2f d2h %.2f ms)" % (
         name, B, t * 1e3, B / t, st["ms_h2d"], st["ms_preprocess"], st["ms_network"], st["ms_decode"] + st["ms_sort"] + st["ms_nms"], st["ms_d2h"]))
+    # pipelined entry (rfd_submit_batch / rfd_collect_batch): two batches in flight, frames in page-locked memory
+    for label, pinned in (("pageable", False), ("page-locked", True)):
+        sets = []
+        for k in range(2):  # two distinct frame sets, as a producer would alternate buffers
+            if pinned:
+                buf = det.host_frames(B, *hw)
+                for i in range(B):
+                    buf[i] = frames[i]
+                sets.append([buf[i] for i in range(B)])
+            else:
+                sets.append([f.copy() for f in frames])
+        det.submit(sets[0])
+        det.submit(sets[1])
+        det.collect()
+        det.collect()
+        steps = 16
+        t0 = time.perf_counter()
+        det.submit(sets[0])
+        for k in range(1, steps):
+            det.submit(sets[k & 1])
+            det.collect()
+        det.collect()
+        t = (time.perf_counter() - t0) / steps
+        print("%-10s source frames, B=%d, pipelined submit/collect, %s frames: %.2f ms/batch = %.0f img/s" % (
+            name, B, label, t * 1e3, B / t))
