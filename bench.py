@@ -24,6 +24,7 @@ for p in (ROOT, os.path.join(ROOT, "rs-face-detection_amd", "python"), os.path.j
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+ASYNC_MODE = int(os.environ.get("RFD_BENCH_ASYNC", "2"))  # 1: every step ordered on one stream; 2: cross-step overlap
 BATCH = int(os.environ.get("RFD_BENCH_BATCH", "32"))  # 32 is the headline configuration
 IMAGE = 640
 MAX_DET = 1024
@@ -127,7 +128,8 @@ def main():
         det.debug_set_concurrency(bool(ms), sp, mp_, bool(gr))
 
     def step():
-        det.detect_device(fptrs, shapes, pb, pl, pc, pt, async_=True)
+        # async 2: the frames are complete in HBM, so the chains of this step may overlap the previous step's tail
+        det.detect_device(fptrs, shapes, pb, pl, pc, pt, async_=ASYNC_MODE)
         if world > 1:
             parallel.gather_detections(slab, out=gathered)
 

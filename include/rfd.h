@@ -189,7 +189,12 @@ RFD_API int rfd_detect_batch(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_det
 /* Same, with every `data` pointer of imgs[] and every pointer of `out` in DEVICE memory (frames
  * already resident in HBM, detections left in HBM for a following RCCL gather).  The imgs[] array
  * itself is host memory.  Enqueued on the context's stream; returns after the stream has drained
- * unless `async` is non-zero (then call rfd_sync before reading results / reusing buffers). */
+ * unless `async` is non-zero (then call rfd_sync before reading results / reusing buffers).
+ * async = 1: the whole call is ordered on the context's stream (frames may be produced by earlier work on it).
+ * async = 2: cross-call overlap -- the frames must be COMPLETE when the call is made (not still being written by
+ *            enqueued work); the network chains then start without waiting for the previous call's decode / NMS, which
+ *            stay on the context's stream together with this call's, so results, rfd_sync and a following collective
+ *            on that stream behave as with async = 1.  Falls back to async = 1 for batches that are not split. */
 RFD_API int rfd_detect_batch_device(rfd_ctx *ctx, const rfd_image *imgs, int n, rfd_dets *out, int async);
 RFD_API int rfd_sync(rfd_ctx *ctx);
 /* Enqueue on a caller-owned hipStream_t instead of the context's own stream (NULL restores it), so

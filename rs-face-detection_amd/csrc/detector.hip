@@ -133,6 +133,11 @@ struct rfd_ctx {
     PipeSlot pipe[kPipe];
     hipStream_t copy_stream = nullptr;
     int pipe_head = 0, pipe_tail = 0, pipe_inflight = 0;
+    // cross-call overlap (rfd_detect_batch_device, async = 2): per-parity descriptors and events
+    DevBuf ov_imgs[2], ov_scale[2];
+    hipEvent_t ov_chain_done[2][2] = {}, ov_post_done[2] = {}, ov_desc = nullptr;
+    bool ov_post_valid[2] = {false, false};
+    int ov_parity = 0;
     rfd_stats stats;
     float conv_ms = 0.f;
     double conv_flops = 0.0;
@@ -291,6 +296,81 @@ int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
     return RFD_OK;
 }
 
+// Cross-call overlap (rfd_detect_batch_device with async = 2; frames and outputs in HBM, frames complete at call time).
+// The two parts of the batch run as chains on their OWN streams (not the caller's): preprocess of the part -> network ->
+// (side streams joined).  Nothing of call i+1 waits for call i except through the chain's own stream order, so the head
+// of chain A of call i+1 overlaps the tail of chain B of call i and the decode / sort / NMS of call i, which stay on the
+// caller's stream behind both chains.  Hazards and how they are closed:
+//   heads, frame descriptors, det_scale : double-buffered by call parity; a chain of call i+2 first waits for the
+//                                          post-processing of call i (ov_post_done) before it touches that parity again
+//   workspace slices, network input       : private to a part, protected by the part stream's order
+//   output slabs (caller's)               : written by NMS on the caller's stream, i.e. in the caller's own order
+int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
+{
+    Network &net = c->net;
+    RFD_TRY(net.ensure_alt_heads());
+    const size_t B = (size_t)c->cfg.max_batch_size;
+    if (!c->ov_desc) {
+        RFD_HIP(hipEventCreateWithFlags(&c->ov_desc, hipEventDisableTiming));
+        for (int a = 0; a < 2; ++a) {
+            RFD_HIP(hipEventCreateWithFlags(&c->ov_post_done[a], hipEventDisableTiming));
+            for (int b = 0; b < 2; ++b) RFD_HIP(hipEventCreateWithFlags(&c->ov_chain_done[a][b], hipEventDisableTiming));
+            RFD_TRY(c->ov_imgs[a].reserve(B * sizeof(PreImage)));
+            RFD_TRY(c->ov_scale[a].reserve(B * sizeof(float)));
+        }
+    }
+    const int par = (c->ov_parity ^= 1);
+    const int slot = c->pin_next;
+    c->pin_next = (c->pin_next + 1) % rfd_ctx::kRing;
+    RFD_HIP(hipEventSynchronize(c->pin_done[slot]));
+    PreImage *pis = c->pin_imgs[slot];
+    for (int i = 0; i < n; ++i) {
+        letterbox(imgs[i].height, imgs[i].width, c->cfg.image_w, c->cfg.image_h, &pis[i], &c->pin_scales[slot][i]);
+        if (pis[i].new_w <= 0 || pis[i].new_h <= 0) {
+            set_error("invalid argument: frame %d (%dx%d) letterboxes to an empty image", i, imgs[i].width, imgs[i].height);
+            return RFD_ERR_INVALID_ARG;
+        }
+        pis[i].src = imgs[i].data;
+        pis[i].stride = (long long)imgs[i].stride;
+    }
+    hipStream_t st[2] = {net.part_stream[0], net.part_stream[1]};
+    if (c->ov_post_valid[par])
+        for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_post_done[par], 0));
+    RFD_HIP(hipMemcpyAsync(c->ov_imgs[par].p, pis, n * sizeof(PreImage), hipMemcpyHostToDevice, st[0]));
+    RFD_HIP(hipMemcpyAsync(c->ov_scale[par].p, c->pin_scales[slot], n * sizeof(float), hipMemcpyHostToDevice, st[0]));
+    RFD_HIP(hipEventRecord(c->pin_done[slot], st[0]));
+    RFD_HIP(hipEventRecord(c->ov_desc, st[0]));
+    RFD_HIP(hipStreamWaitEvent(st[1], c->ov_desc, 0));
+    net.head_parity = par;
+    net.co_running = 1;
+    const int B0 = (n + 1) / 2;
+    const size_t in_px = (size_t)c->cfg.image_h * c->cfg.image_w * 4;
+    int status = RFD_OK;
+    for (int p = 0; p < 2 && status == RFD_OK; ++p) {
+        const int off = p ? B0 : 0, Bp = p ? n - B0 : B0;
+        PreParams pp;
+        memset(&pp, 0, sizeof pp);
+        pp.imgs = (const PreImage *)c->ov_imgs[par].p + off;
+        pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
+        pp.out_nhwc4 = (bf16_t *)net.tensor_ptr(net.g.input) + (size_t)off * in_px;
+        status = launch_preprocess(pp, Bp, st[p]);
+        if (status == RFD_OK) status = net.run(Bp, st[p], 0, -1, off, p);
+        if (status == RFD_OK && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
+    }
+    net.co_running = 0;
+    if (status != RFD_OK) { net.head_parity = 0; return status; }
+    for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(c->stream, c->ov_chain_done[par][p], 0));
+    DecodeParams dp;
+    fill_decode_params(c, dp);
+    for (int l = 0; l < kNumLevels; ++l) dp.cls[l] = (const float *)net.tensor_ptr(net.g.heads[l]);
+    net.head_parity = 0;
+    RFD_TRY(post_network(c, dp, false, n, out->boxes, out->landmarks, out->count, out->total, nullptr,
+                         (const float *)c->ov_scale[par].p));
+    RFD_HIP(hipEventRecord(c->ov_post_done[par], c->stream));
+    c->ov_post_valid[par] = true;
+    return RFD_OK;
+}
+
 int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on_device, int async, bool frames_on_device)
 {
     RFD_CHECK_ARG(c != nullptr, "ctx is null");
@@ -298,6 +378,10 @@ int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on
     RFD_TRY(check_images(c, imgs, n));
     RFD_TRY(c->ensure_network());
     if (!c->net.weights_ready) { set_error("network weights are not initialised"); return RFD_ERR_STATE; }
+    if (async == 2 && on_device && frames_on_device && !c->net.profiling && c->net.multi_stream && c->net.num_parts(n) == 2) {
+        RFD_HIP(hipSetDevice(c->cfg.device_id));
+        return detect_overlapped(c, imgs, n, out);
+    }
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     std::vector<float> scales;
     RFD_HIP(hipEventRecord(c->ev[0], c->stream));
@@ -423,7 +507,7 @@ void rfd_destroy(rfd_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize(); // part / side / copy streams included
     if (c->net_created) c->net.destroy();
     DevBuf *bufs[] = {&c->staging, &c->imgs, &c->in4, &c->rows, &c->keys, &c->sorted_keys, &c->sorted_boxes,
                       &c->count, &c->det_scale, &c->out_boxes, &c->out_lmk, &c->out_count, &c->out_total,
@@ -448,6 +532,13 @@ void rfd_destroy(rfd_ctx *c)
         if (ps.h2d) (void)hipEventDestroy(ps.h2d);
         if (ps.done) (void)hipEventDestroy(ps.done);
     }
+    for (int a = 0; a < 2; ++a) {
+        c->ov_imgs[a].release(); c->ov_scale[a].release();
+        if (c->ov_post_done[a]) (void)hipEventDestroy(c->ov_post_done[a]);
+        for (int b = 0; b < 2; ++b)
+            if (c->ov_chain_done[a][b]) (void)hipEventDestroy(c->ov_chain_done[a][b]);
+    }
+    if (c->ov_desc) (void)hipEventDestroy(c->ov_desc);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

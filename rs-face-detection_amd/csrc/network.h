@@ -103,10 +103,24 @@ struct Network {
     void *tensor_ptr(int t, int batch_off = 0) const
     {
         const int bi = g.tensors[t].buffer;
-        return (char *)d_buffers[bi] + (size_t)batch_off * g.buffer_bytes_per_image[bi];
+        void *base = (head_parity && bi < (int)d_alt.size() && d_alt[bi]) ? d_alt[bi] : d_buffers[bi];
+        return (char *)base + (size_t)batch_off * g.buffer_bytes_per_image[bi];
     }
+    // second copy of the three head buffers: with calls overlapped across steps (rfd_detect_batch_device, async = 2)
+    // the chains of call i+1 write heads[parity ^ 1] while decode of call i still reads heads[parity]
+    std::vector<void *> d_alt;
+    int head_parity = 0;
+    int ensure_alt_heads();
     int run(int B, hipStream_t s, int first_op = 0, int last_op = -1, int batch_off = 0, int part = 0);
     int run_split(int B, hipStream_t s); // whole pass; splits the batch over several streams when it pays
+    int split_body(int B, int P, hipStream_t s);
+    int tune_streams(int B, int P, hipStream_t s);
+    void assign_streams(int a, int b);
+    static constexpr int kPool = 8;
+    hipStream_t pool[kPool] = {};
+    bool tuned = false, tune = true;
+    float tuned_ms = 0.f;
+    int tuned_a = -1, tuned_b = -1;
     // whole op list replayed from a hipGraph captured per batch size (removes ~5 us of launch gap per kernel;
     // matters at batch 1, where the network is launch-bound); falls back to run() while profiling
     int run_graphed(int B, hipStream_t s);
@@ -124,7 +138,7 @@ struct Network {
     // quantisation at B = 32 costs ~10 %: B = 256 measures 6.0 k img/s vs 5.5 k unsplit).  A split pass is always
     // launched eagerly: replayed from a hipGraph it measured SLOWER than the unsplit graph (5.07 k vs 5.46 k img/s at
     // B = 32; eager split 6.07 k), and launch gaps are hidden at these batch sizes anyway.
-    hipStream_t part_stream[kMaxParts] = {}; // [0] unused (part 0 runs on the caller's stream)
+    hipStream_t part_stream[kMaxParts] = {}; // [0]: only the cross-call overlap mode runs part 0 off the caller's stream
     hipEvent_t ev_part_fork = nullptr, ev_part_join[kMaxParts] = {};
     int co_running = 0;      // set while the parts of a split pass are being enqueued
     int split_min_part = 4;  // fewest images a part may hold (B = 8: 4.02 k img/s split vs 3.86 k as one graph; B <= 6: graph wins or ties)

@@ -382,7 +382,7 @@ class RetinaFaceDetection:
         for i, (p, (h, w)) in enumerate(zip(frame_ptrs, shapes)):
             arr[i].data, arr[i].height, arr[i].width, arr[i].stride = p, h, w, w * 3
         d = rfd_dets(out_boxes_ptr, out_lmk_ptr, out_count_ptr, out_total_ptr)
-        _check(self._L.rfd_detect_batch_device(self._ctx, arr, n, C.byref(d), 1 if async_ else 0))
+        _check(self._L.rfd_detect_batch_device(self._ctx, arr, n, C.byref(d), int(async_)))  # 0 sync, 1 async, 2 overlapped
 
     def sync(self):
         _check(self._L.rfd_sync(self._ctx))

@@ -22,6 +22,9 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def rfd():
+    # torch bundles its own libamdhip64; loading it FIRST makes librfd_hip.so bind to that same copy (same SONAME).
+    # The other order puts two HIP runtimes into one process, and whichever initialises second may find no device.
+    import torch  # noqa: F401
     import rfd_hip
     rfd_hip.load_library()  # raises if librfd_hip.so is missing: no CPU fallback
     return rfd_hip

@@ -107,3 +107,41 @@ def test_independent_contexts_overlap_exactly(rfd):
             assert torch.equal(slab.buf, r)
     for det, _ in ctxs:
         det.close()
+
+
+@pytest.mark.parametrize("backbone", ["r50", "mnet025"])
+def test_cross_call_overlap_is_exact(rfd, backbone):
+    """rfd_detect_batch_device(async = 2): the chains of call i+1 start while call i's tail / decode / NMS still run.
+    Alternating frame sets and output slabs; every call must reproduce its synchronous result."""
+    import torch
+    from rfd_hip import parallel
+    bb = rfd.BACKBONE_R50 if backbone == "r50" else rfd.BACKBONE_MNET025
+    n = 9
+    dev = torch.device("cuda", 0)
+    det = rfd.RetinaFaceDetection(max_batch_size=n, max_det=512, confidence_threshold=0.3, backbone=bb)
+    det.init_synthetic_weights(1234)
+    sets, refs = [], []
+    for k in range(3):
+        fr = torch.from_numpy(np.stack([helpers.make_image(500 + 20 * k + i, 640, 640, n_blobs=4) for i in range(n)])).to(dev)
+        sets.append((fr, [fr.data_ptr() + i * 640 * 640 * 3 for i in range(n)]))
+    slabs = [parallel.DetectionSlab(n, 512, device=dev) for _ in range(3)]
+    for (fr, ptrs), slab in zip(sets, slabs):
+        det.detect_device(ptrs, [(640, 640)] * n, *slab.pointers(), async_=0)
+        refs.append(slab.buf.clone())
+    assert int(slabs[0].count().sum()) > 0 and not torch.equal(refs[0], refs[1])
+    outs = [parallel.DetectionSlab(n, 512, device=dev) for _ in range(3)]
+    for rnd in range(4):
+        for o in outs:
+            o.buf.zero_()
+        torch.cuda.synchronize()
+        for step in range(9):                      # 9 calls back to back, three of them in flight per output slab
+            k = (step + rnd) % 3
+            det.detect_device(sets[k][1], [(640, 640)] * n, *outs[k].pointers(), async_=2)
+        det.sync()
+        for k in range(3):
+            assert torch.equal(outs[k].buf, refs[k]), (rnd, k)
+        # mixing with the ordinary modes afterwards
+        det.detect_device(sets[0][1], [(640, 640)] * n, *outs[1].pointers(), async_=1)
+        det.sync()
+        assert torch.equal(outs[1].buf, refs[0])
+    det.close()
