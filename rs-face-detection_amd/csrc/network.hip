@@ -4,6 +4,8 @@
 #include "network.h"
 
 #include <math.h>
+#include <algorithm>
+#include <utility>
 
 namespace rfd {
 
@@ -803,21 +805,36 @@ int Network::tune_streams(int B, int P, hipStream_t s)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     RFD_HIP(hipEventCreate(&e0));
     RFD_HIP(hipEventCreate(&e1));
-    float best = 1e30f;
-    int ba = 2, bb = 5, st = RFD_OK;
+    int st = RFD_OK;
+    auto time_pair = [&](int a, int b, int reps, float *out) { // median of `reps` synchronous passes after one warm pass
+        assign_streams(a, b);
+        std::vector<float> ts;
+        for (int rep = 0; rep <= reps && st == RFD_OK; ++rep) {
+            if (hipEventRecord(e0, s) != hipSuccess) st = RFD_ERR_HIP;
+            if (st == RFD_OK) st = split_body(B, P, s);
+            if (st == RFD_OK && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) st = RFD_ERR_HIP;
+            float ms = 0.f;
+            if (st == RFD_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0) ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+        *out = ts.empty() ? 1e30f : ts[ts.size() / 2];
+    };
+    // coarse scan of all pairs (2 passes each), then the four best again with 9 passes each
+    std::vector<std::pair<float, std::pair<int, int>>> cand;
     for (int a = 0; a < kPool && st == RFD_OK; ++a)
         for (int b = a + 1; b < kPool && st == RFD_OK; ++b) {
-            assign_streams(a, b);
-            float t = 1e30f;
-            for (int rep = 0; rep < 3 && st == RFD_OK; ++rep) {
-                if (hipEventRecord(e0, s) != hipSuccess) st = RFD_ERR_HIP;
-                if (st == RFD_OK) st = split_body(B, P, s);
-                if (st == RFD_OK && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) st = RFD_ERR_HIP;
-                float ms = 0.f;
-                if (st == RFD_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0) t = std::min(t, ms);
-            }
-            if (t < best) { best = t; ba = a; bb = b; }
+            float t;
+            time_pair(a, b, 2, &t);
+            cand.push_back({t, {a, b}});
         }
+    std::sort(cand.begin(), cand.end());
+    float best = 1e30f;
+    int ba = 2, bb = 5;
+    for (size_t i = 0; i < cand.size() && i < 4 && st == RFD_OK; ++i) {
+        float t;
+        time_pair(cand[i].second.first, cand[i].second.second, 9, &t);
+        if (t < best) { best = t; ba = cand[i].second.first; bb = cand[i].second.second; }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     RFD_TRY(st);
