@@ -84,7 +84,7 @@ def pmc(fetch_db, write_db, out_json):
         return per, calls
     fetch, calls = load(fetch_db, "FETCH_SIZE")
     write, _ = load(write_db, "WRITE_SIZE")
-    passes = max(calls.get("rfd::preprocess_kernel", 0), 1)
+    passes = max(calls.get("rfd::decode_kernel<false>", 0), 1)  # exactly one per pass in every execution mode
     rows, nf, nw = {}, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         f = 2.0 * fetch.get(k, 0.0) * 1024 / passes
@@ -100,8 +100,38 @@ def pmc(fetch_db, write_db, out_json):
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
 
 
+def mfma(db_path, out_json):
+    """MFMA pipe utilisation per network kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over all SIMDs) over the
+    kernel's own cycles x 1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)."""
+    db = sqlite3.connect(db_path)
+    acc = {}
+    for n, c, v in db.execute("select kernel_name, counter_name, value from counters_collection"):
+        k = short(n)
+        if not is_net(k):
+            continue
+        a = acc.setdefault(k, {})
+        a[c] = a.get(c, 0.0) + v
+        a["_n_" + c] = a.get("_n_" + c, 0) + 1
+    rows, tb, tc = {}, 0.0, 0.0
+    for k, a in acc.items():
+        busy, gui = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
+        cyc = gui / 8.0
+        rows[k] = {"dispatches": a.get("_n_GRBM_GUI_ACTIVE", 0), "mfma_busy_cycles": busy, "kernel_cycles": cyc,
+                   "mfma_util": busy / (cyc * 1024.0) if cyc else None}
+        tb += busy
+        tc += cyc
+    out = {"network_mfma_util": tb / (tc * 1024.0) if tc else None,
+           "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); kernels profiled one dispatch at a time",
+           "kernels": rows}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps({"network_mfma_util": out["network_mfma_util"],
+                      "per_kernel": {k: round(v["mfma_util"], 4) for k, v in rows.items() if v["mfma_util"] is not None}}))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
