@@ -27,6 +27,8 @@ import torch  # noqa: E402
 ASYNC_MODE = int(os.environ.get("RFD_BENCH_ASYNC", "2"))  # 1: every step ordered on one stream; 2: cross-step overlap
 BATCH = int(os.environ.get("RFD_BENCH_BATCH", "32"))  # 32 is the headline configuration
 IMAGE = 640
+# source frame size (h, w); default = the network size.  RFD_BENCH_SRC=1080x1920 gives BASELINE.json configs[3]'s per-GPU slice
+SRC_H, SRC_W = (int(v) for v in os.environ.get("RFD_BENCH_SRC", "640x640").split("x"))
 MAX_DET = 1024
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 TARGET_CAND_RATE = 0.006   # ~100 candidates / image, a realistic operating point
@@ -110,11 +112,11 @@ def main():
     graph = rfd_hip.Graph(rfd_hip.BACKBONE_R50, IMAGE, IMAGE)
 
     # synthetic 640x640 BGR frames (seed 1 + global image index), resident in HBM
-    frames_np = [helpers.make_image(1000 + rank * BATCH + i, IMAGE, IMAGE) for i in range(BATCH)]
+    frames_np = [helpers.make_image(1000 + rank * BATCH + i, SRC_H, SRC_W) for i in range(BATCH)]
     delta = calibrate_cls_bias(det, graph, frames_np)
     frames = torch.from_numpy(np.stack(frames_np)).to(dev)
-    fptrs = [frames.data_ptr() + i * IMAGE * IMAGE * 3 for i in range(BATCH)]
-    shapes = [(IMAGE, IMAGE)] * BATCH
+    fptrs = [frames.data_ptr() + i * SRC_H * SRC_W * 3 for i in range(BATCH)]
+    shapes = [(SRC_H, SRC_W)] * BATCH
     slab = parallel.DetectionSlab(BATCH, MAX_DET, device=dev)
     pb, pl, pc, pt = slab.pointers()
     gathered = torch.empty(world * slab.words, dtype=torch.int32, device=dev) if world > 1 else None
@@ -217,7 +219,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "RetinaFace-ResNet50 640x640 batch=32 bf16 per GPU (BASELINE.json configs[2])",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [IMAGE, IMAGE],
-                       "source_frames": "640x640x3 u8 synthetic, resident in HBM", "max_det": MAX_DET,
+                       "source_frames": "%dx%dx3 u8 synthetic, resident in HBM" % (SRC_W, SRC_H), "max_det": MAX_DET,
                        "weights": "seeded synthetic (no model file exists in the reference), cls bias calibrated %+.3f" % delta,
                        "parallelism": "image-parallel x%d, RCCL all-gather of detection slabs" % world if world > 1 else "single GPU",
                        "candidates_per_image": round(float(stats["candidates"]) / BATCH, 1),
