@@ -154,7 +154,22 @@ __global__ void __launch_bounds__(256) rank_sort_kernel(const uint64_t *__restri
         tile[threadIdx.x] = j < n ? k[j] : ~0ull;
         __syncthreads();
         const int lim = min(256, n - t0);
-        for (int jj = 0; jj < lim; ++jj) rank += tile[jj] < mine ? 1 : 0;
+        // every lane reads the same key: a broadcast.  Read as 64-bit words (volatile keeps the compiler from fusing two
+        // keys into one ds_read_b128): broadcast ds_read_b128 is the one LDS read shape that was seen returning wrong
+        // lanes next to the LDS-DMA conv kernels of another stream (DESIGN.md "concurrency"); a register + v_readlane
+        // version without LDS measured 3x slower on dense crowds.
+        const uint32_t base = (uint32_t)(uintptr_t)tile; // LDS byte offset (low half of the generic address)
+        for (int j0 = 0; j0 < lim; j0 += 8) {            // slots >= lim of the last tile hold ~0: never < mine
+            uint64_t v[8];
+            asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:8\n ds_read_b64 %2, %8 offset:16\n"
+                         "ds_read_b64 %3, %8 offset:24\n ds_read_b64 %4, %8 offset:32\n ds_read_b64 %5, %8 offset:40\n"
+                         "ds_read_b64 %6, %8 offset:48\n ds_read_b64 %7, %8 offset:56\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(base + (uint32_t)j0 * 8u)
+                         : "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rank += v[q] < mine ? 1 : 0;
+        }
         __syncthreads();
     }
     if (i < n) {
@@ -194,6 +209,23 @@ constexpr int kNmsWaves = kNmsThreads / 64;
 constexpr int kNmsRegWords = 17;    // bitmap words (64 candidates each) a wave can own in registers
 constexpr int kNmsRegCap = kNmsRegWords * kNmsWaves * 64; // 17408 >= the 16800 anchors of a 640x640 input
 constexpr int kNmsLdsBoxes = 4096;  // REG = false only: sorted boxes cached in LDS, the rest stream from L2
+
+// the float4 held by lane `src` (wave-uniform) of this wave
+__device__ __forceinline__ float4 lane_box(const float4 v, int src)
+{
+    return make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), src)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), src)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), src)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), src)));
+}
+
+// broadcast read of one box from LDS as two 64-bit reads (not one ds_read_b128: see rank_sort_kernel)
+__device__ __forceinline__ float4 lds_box_2x64(uint32_t lds_byte_addr)
+{
+    float2 a, b;
+    asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(lds_byte_addr) : "memory");
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 
 __device__ __forceinline__ float box_area(const float4 b)
 {
@@ -286,8 +318,9 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
                 while (cand != 0ull) { // wave-uniform walk over the alive candidates only
                     const int jj = __builtin_ctzll(cand);
                     cand &= cand - 1ull;
-                    // same address in every lane: a broadcast
-                    const float4 other = tile_boxes[jj];
+                    // box jj lives in lane jj of this wave: cross-lane read, no LDS (wide broadcast LDS reads are kept
+                    // out of kernels that may share a CU with LDS-DMA conv kernels, DESIGN.md "concurrency")
+                    const float4 other = lane_box(box, jj);
                     if (jj > lane && suppresses(box, area, other, box_area(other), thresh)) mask |= 1ull << jj;
                 }
                 // greedy resolve in score order; `alive` is wave-uniform
@@ -308,6 +341,7 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
         const uint64_t kmask = kept_word[0];
         if (kmask != 0ull) {
             // every wave owns whole bitmap words: one ballot, one plain LDS store, no atomics
+            const uint32_t tile_base = (uint32_t)(uintptr_t)tile_boxes; // LDS byte offset of the tile
             auto scan_word = [&](int w, const float4 bj) {
                 const uint64_t rw = removed[w];
                 if (rw == ~0ull) return; // wave-uniform
@@ -317,7 +351,7 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
                 while (km != 0ull) { // wave-uniform trip count; ONE LDS broadcast per step (area recomputed:
                     const int i = __builtin_ctzll(km); // a second LDS read per step measured 45 % slower)
                     km &= km - 1ull;
-                    const float4 bi = tile_boxes[i];
+                    const float4 bi = lds_box_2x64(tile_base + (uint32_t)i * 16u);
                     sup |= suppresses(bi, box_area(bi), bj, area_j, thresh);
                 }
                 const uint64_t bal = __ballot(sup);
