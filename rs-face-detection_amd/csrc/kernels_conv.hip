@@ -1082,8 +1082,8 @@ int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const fl
 // ------------------------------------------------------------------------------------------------
 // The 288 weights are wave-uniform and indexed by compile-time constants, so they are fetched with scalar loads
 // (s_load_dwordxN of bf16 pairs) straight into SGPRs -- no LDS table.  (An earlier version kept them as floats in LDS
-// and read them with broadcast ds_read_b128; on MI355X those reads returned wrong data in lanes 48..63 whenever a
-// conv workgroup of ANOTHER stream, streaming its tiles in with LDS-DMA, shared the CU -- see DESIGN.md, "concurrency".)
+// and read them with broadcast ds_read_b128; on MI355X those reads returned wrong data in lanes 48..63 whenever
+// MFMA-issuing waves of ANOTHER kernel (a conv of another stream) shared the CU -- see DESIGN.md, "concurrency".)
 __global__ void __launch_bounds__(256) first3x3_kernel(const bf16_t *__restrict__ x4, const uint32_t *__restrict__ w2, // [8][3][3][4] bf16 as pairs
                                                        const float *__restrict__ bias, bf16_t *__restrict__ y, int B,
                                                        int H, int W, int Ho, int Wo, int Cd)

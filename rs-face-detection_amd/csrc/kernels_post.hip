@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) rank_sort_kernel(const uint64_t *__restri
         const int lim = min(256, n - t0);
         // every lane reads the same key: a broadcast.  Read as 64-bit words (volatile keeps the compiler from fusing two
         // keys into one ds_read_b128): broadcast ds_read_b128 is the one LDS read shape that was seen returning wrong
-        // lanes next to the LDS-DMA conv kernels of another stream (DESIGN.md "concurrency"); a register + v_readlane
+        // lanes next to the MFMA conv kernels of another stream (DESIGN.md "concurrency"); a register + v_readlane
         // version without LDS measured 3x slower on dense crowds.
         const uint32_t base = (uint32_t)(uintptr_t)tile; // LDS byte offset (low half of the generic address)
         for (int j0 = 0; j0 < lim; j0 += 8) {            // slots >= lim of the last tile hold ~0: never < mine
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
                     const int jj = __builtin_ctzll(cand);
                     cand &= cand - 1ull;
                     // box jj lives in lane jj of this wave: cross-lane read, no LDS (wide broadcast LDS reads are kept
-                    // out of kernels that may share a CU with LDS-DMA conv kernels, DESIGN.md "concurrency")
+                    // out of kernels that may share a CU with MFMA conv kernels of another stream, DESIGN.md "concurrency")
                     const float4 other = lane_box(box, jj);
                     if (jj > lane && suppresses(box, area, other, box_area(other), thresh)) mask |= 1ull << jj;
                 }

@@ -40,8 +40,8 @@ def _same(got, ref):
 
 @pytest.mark.parametrize("victim,disturber", [("mnet025", "mnet025"), ("r50", "mnet025"), ("mnet025", "r50"), ("r50", "r50")])
 def test_pipeline_is_exact_while_another_context_runs_convs(rfd, victim, disturber):
-    """Regression for a cross-workgroup hazard seen on MI355X: with a conv workgroup of ANOTHER stream (LDS-DMA tile
-    loads) on the same CU, broadcast ds_read_b128 reads of the old MobileNet first-conv weight table returned wrong
+    """Regression for a cross-workgroup hazard seen on MI355X: with MFMA-issuing waves of ANOTHER kernel (a conv of another
+    stream) on the same CU, broadcast ds_read_b128 reads of the old MobileNet first-conv weight table returned wrong
     data in lanes 48..63.  A second context keeps conv kernels in flight from another thread while the victim runs
     its whole pipeline; every result must stay bit-identical to the undisturbed one."""
     import threading

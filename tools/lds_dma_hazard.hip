@@ -1,20 +1,31 @@
-// lds_dma_hazard.hip -- micro-test written while chasing a cross-workgroup problem on gfx950 (MI355X, ROCm 7.0
-// runtime): the old MobileNet first-conv kernel kept its 288 weights as floats in LDS and read them with broadcast
-// ds_read_b128; whenever a conv workgroup of ANOTHER stream (tiles streamed in with LDS-DMA, buffer_load_dwordx4 ...
-// lds) shared the CU, ~1e-4 of those wave reads returned wrong data, always in lanes 48..63 and only for the b128
-// reads (the ds_read_b96 reads of the same table, and a build without ds_read_b128, were clean).
+// lds_dma_hazard.hip -- stand-alone reproducer of a cross-wave problem met on gfx950 (MI355X, ROCm 7.0 runtime).
 //
-// RESULT OF THIS PROGRAM: it does NOT reproduce the problem -- every read shape below comes back clean, with the
-// synthetic disturbers here and with the real conv kernels of librfd_hip.so in flight (tools/_hazard_with_conv.py).
-// The trigger therefore needs something of the real kernel that is not modelled here; the product avoids it by
-// keeping wave-uniform tables out of LDS (scalar loads) and tests/test_concurrency_gpu.py guards the pipeline.
+// Symptom: the old MobileNet first-conv kernel kept its 288 weights as floats in LDS and read them with broadcast
+// ds_read_b128 (all lanes, same address).  Whenever waves of ANOTHER kernel that issue MFMAs were resident on the same
+// CU, some of its outputs were wrong -- always in lanes 48..63 of a wave, only in the channels fed by ds_read_b128.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o lds_dma_hazard tools/lds_dma_hazard.hip && ./lds_dma_hazard
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/bin/liblds_dma_hazard.so tools/lds_dma_hazard.hip
+// What this program establishes (run it: the table it prints is the evidence; numbers from one MI355X):
+//   * victim = that kernel (victim_f3<0>, compiler-chosen reads) or the same kernel with explicit broadcast
+//     ds_read_b128 and a full s_waitcnt lgkmcnt(0) before any arithmetic (victim_f3<3>): 10^4..10^6 wrong elements per
+//     run, all in lane quarter 3;  the same kernel reading the table as 2 x ds_read_b64 (victim_f3<4>): ZERO;
+//   * disturber = any kernel issuing v_mfma_f32_16x16x32_bf16: LDS-DMA + fragment reads + MFMA (the conv kernels'
+//     loop shape), fragment reads + MFMA without DMA, and MFMA on register operands with no LDS traffic at all;
+//     LDS-DMA or LDS traffic WITHOUT MFMA does not trigger it (the file name records the first, wrong suspicion);
+//   * plain read-and-compare victims of every shape (broadcast / per-lane / fragment b128, b96, b64, b32, eight reads in
+//     flight, with a global load pending) stay clean under every disturber -- so what the first-conv kernel adds to
+//     "a broadcast ds_read_b128" is still not isolated.
+// The product therefore keeps broadcast operands out of ds_read_b128: scalar loads for weight tables, 64-bit LDS reads
+// or v_readlane in sort / NMS (tests/test_concurrency_gpu.py guards the pipeline).  The conv kernels' own per-lane
+// fragment ds_read_b128 next to their own MFMAs are not affected (bit-identical results in every execution mode).
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o lds_dma_hazard tools/lds_dma_hazard.hip && ./lds_dma_hazard
+//   hipcc ... -shared -fPIC -o tools/bin/liblds_dma_hazard.so tools/lds_dma_hazard.hip   (tools/_hazard_with_conv.py:
+//   the same victims with the real conv kernels of librfd_hip.so as the disturber)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -26,18 +37,24 @@ template <int MODE> __global__ void __launch_bounds__(256) disturber(const uint3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(src), 0, (uint32_t)n_bytes, 0x00020000);
     uint32_t acc = 0;
+    typedef __attribute__((ext_vector_type(4))) float macc_t;
+    macc_t macc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) macc[a][b] = macc_t{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
         const uint32_t base = (uint32_t)(((size_t)(blockIdx.x * 131 + it) * 4096) % (n_bytes - 65536));
         for (int q = 0; q < 8; ++q) {
             unsigned char *dst = smem + (wave * 8 + q) * 1024;
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 3 || MODE == 4) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16,
                                                          base + (wave * 8 + q) * 1024 + lane * 16, 0, 0, 0);
             } else if (MODE == 1) {
                 for (int k = 0; k < 4; ++k)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(dst + k * 256), 4,
                                                              base + (wave * 8 + q) * 1024 + k * 256 + lane * 4, 0, 0, 0);
-            } else {
+            } else if (MODE == 2) {
                 const uint4 v = *reinterpret_cast<const uint4 *>((const char *)src + base + (wave * 8 + q) * 1024 + lane * 16);
                 *reinterpret_cast<uint4 *>(dst + lane * 16) = v;
             }
@@ -45,7 +62,40 @@ template <int MODE> __global__ void __launch_bounds__(256) disturber(const uint3
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         acc += *reinterpret_cast<const uint32_t *>(smem + ((threadIdx.x * 52 + it * 4) & 32764));
+        if (MODE >= 3) { // the conv kernels' inner loop shape: 16 fragment ds_read_b128 (+ 32 MFMAs in mode 4) per step
+            typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+            typedef __attribute__((ext_vector_type(4))) float f4;
+            const int frow = lane & 15, fq = lane >> 4;
+            bf8 af[4], bf[4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = t * 16 + frow, ch = kk * 4 + fq;
+                    if (MODE == 6 && it > 0) continue; // MFMA on register operands only: the fragments are read once
+                    af[t] = *reinterpret_cast<const bf8 *>(smem + (wave * 4096) + r * 128 + ((ch ^ (r & 7)) << 4));
+                    bf[t] = *reinterpret_cast<const bf8 *>(smem + 16384 + (wave * 4096) + r * 128 + ((ch ^ (r & 7)) << 4));
+                }
+                if (MODE >= 4) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) macc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], macc[a][b], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc += __builtin_bit_cast(uint4, af[t]).x ^ __builtin_bit_cast(uint4, bf[t]).y;
+                }
+            }
+        }
         __syncthreads();
+    }
+    if (MODE >= 4) {
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t += macc[a][b][0] + macc[a][b][3];
+        if (t == 123.456f) sink[1] = 1;
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
@@ -140,6 +190,10 @@ template <int SHAPE> static void run_victim(const char *name, int dmode, const u
     if (dmode == 0) hipLaunchKernelGGL(disturber<0>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
     else if (dmode == 1) hipLaunchKernelGGL(disturber<1>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
     else if (dmode == 2) hipLaunchKernelGGL(disturber<2>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
+    else if (dmode == 4) hipLaunchKernelGGL(disturber<3>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
+    else if (dmode == 5) hipLaunchKernelGGL(disturber<4>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
+    else if (dmode == 6) hipLaunchKernelGGL(disturber<5>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
+    else if (dmode == 7) hipLaunchKernelGGL(disturber<6>, dim3(dgrid), dim3(256), 32768, sa, src, nbytes, diters, sink);
     for (int rep = 0; rep < 4; ++rep) hipLaunchKernelGGL(victim<SHAPE>, dim3(4096), dim3(256), 0, sb, 2000, d_bad);
     CK(hipDeviceSynchronize());
     unsigned long long h[64];
@@ -147,6 +201,171 @@ template <int SHAPE> static void run_victim(const char *name, int dmode, const u
     unsigned long long tot = 0, q[4] = {0, 0, 0, 0};
     for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
     printf("  %-44s bad reads %10llu   by lane quarter [%llu %llu %llu %llu]\n", name, tot, q[0], q[1], q[2], q[3]);
+}
+
+
+// ---- the kernel in which the problem was first seen (the MobileNet first conv with its weights as floats in LDS),
+//      as a victim: run against a reference computed without a disturber ----
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+typedef __attribute__((ext_vector_type(4))) __bf16 hz_bf16x4;
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
+{
+    hz_bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+template <int VARIANT>
+__global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4, const uint16_t *__restrict__ w, // [8][3][3][4]
+                                                       const float *__restrict__ bias, uint16_t *__restrict__ y, int B,
+                                                       int H, int W, int Ho, int Wo, int Cd)
+{
+    // VARIANT 0: as shipped then (1152 B of LDS, compiler-chosen ds_read_b128/b96); 1: LDS allocation padded to 8 KiB;
+    // 2: table placed 4 KiB into the allocation
+    __shared__ __attribute__((aligned(16))) float ws_all[(VARIANT == 1 || VARIANT == 2) ? 2048 : 8 * 36];
+    float *ws = ws_all + (VARIANT == 2 ? 1024 : 0);
+    if (VARIANT == 1) ws_all[2047 - (threadIdx.x & 255)] = 0.f;
+    for (int i = threadIdx.x; i < 8 * 36; i += 256) ws[i] = bf16_bits_to_f32(w[i]);
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * Ho * Wo) return;
+    const int wo = (int)(i % Wo);
+    const int ho = (int)((i / Wo) % Ho);
+    const int b = (int)(i / ((long long)Wo * Ho));
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = bias[c];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hi = 2 * ho - 1 + ky;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int wi = 2 * wo - 1 + kx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint2 p = reinterpret_cast<const uint2 *>(x4)[((long long)b * H + hi) * W + wi];
+            const float r = bf16_bits_to_f32(p.x & 0xffffu), g = bf16_bits_to_f32(p.x >> 16), bl = bf16_bits_to_f32(p.y & 0xffffu);
+            if (VARIANT >= 3) {
+                // 3: the tap's 8 weight vectors by explicit broadcast ds_read_b128, ALL landed (lgkmcnt(0)) before any
+                //    arithmetic; 4: the same with ds_read_b64 pairs; 5: b128, but the arithmetic of channel c starts
+                //    while the reads of the later channels are still in flight (counted waits)
+                typedef __attribute__((ext_vector_type(4))) float f4;
+                typedef __attribute__((ext_vector_type(2))) float f2;
+                const uint32_t a0 = (uint32_t)(uintptr_t)ws + (uint32_t)(ky * 3 + kx) * 16u;
+                f4 wv[8];
+                if (VARIANT == 4) {
+                    f2 l0, l1, l2, l3, l4, l5, l6, l7, h0, h1, h2, h3, h4, h5, h6, h7;
+                    asm volatile("ds_read_b64 %0, %16\n ds_read_b64 %8, %16 offset:8\n ds_read_b64 %1, %16 offset:144\n ds_read_b64 %9, %16 offset:152\n"
+                                 "ds_read_b64 %2, %16 offset:288\n ds_read_b64 %10, %16 offset:296\n ds_read_b64 %3, %16 offset:432\n ds_read_b64 %11, %16 offset:440\n"
+                                 "ds_read_b64 %4, %16 offset:576\n ds_read_b64 %12, %16 offset:584\n ds_read_b64 %5, %16 offset:720\n ds_read_b64 %13, %16 offset:728\n"
+                                 "ds_read_b64 %6, %16 offset:864\n ds_read_b64 %14, %16 offset:872\n ds_read_b64 %7, %16 offset:1008\n ds_read_b64 %15, %16 offset:1016\n"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(l4), "=&v"(l5), "=&v"(l6), "=&v"(l7),
+                                   "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5), "=&v"(h6), "=&v"(h7)
+                                 : "v"(a0) : "memory");
+                    wv[0] = f4{l0.x, l0.y, h0.x, h0.y}; wv[1] = f4{l1.x, l1.y, h1.x, h1.y}; wv[2] = f4{l2.x, l2.y, h2.x, h2.y};
+                    wv[3] = f4{l3.x, l3.y, h3.x, h3.y}; wv[4] = f4{l4.x, l4.y, h4.x, h4.y}; wv[5] = f4{l5.x, l5.y, h5.x, h5.y};
+                    wv[6] = f4{l6.x, l6.y, h6.x, h6.y}; wv[7] = f4{l7.x, l7.y, h7.x, h7.y};
+                } else if (VARIANT == 3) {
+                    asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
+                                 "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7])
+                                 : "v"(a0) : "memory");
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(wv[c]) : "v"(a0 + (uint32_t)c * 144u) : "memory");
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (VARIANT == 5) {
+                        // wait until read c has landed (7 - c younger reads may still be in flight)
+                        switch (c) {
+                        case 0: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(wv[0]) :: "memory"); break;
+                        case 1: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wv[1]) :: "memory"); break;
+                        case 2: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(wv[2]) :: "memory"); break;
+                        case 3: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wv[3]) :: "memory"); break;
+                        case 4: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wv[4]) :: "memory"); break;
+                        case 5: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wv[5]) :: "memory"); break;
+                        case 6: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wv[6]) :: "memory"); break;
+                        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[7]) :: "memory"); break;
+                        }
+                    }
+                    acc[c] += r * wv[c].x + g * wv[c].y + bl * wv[c].z;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float *wc = ws + c * 36 + (ky * 3 + kx) * 4;
+                    acc[c] += r * wc[0] + g * wc[1] + bl * wc[2];
+                }
+            }
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(y + i * Cd);
+    const uint2 lo = pack_bf16x4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    const uint2 hi2 = pack_bf16x4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+    dst[0] = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+    for (int k = 1; k < Cd / 8; ++k) dst[k] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ void hz_compare(const uint16_t *a, const uint16_t *b, size_t n_px, int Cd, unsigned long long *bad_by_lane)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; // pixel
+    if (i >= n_px) return;
+    unsigned bad = 0;
+    for (int c = 0; c < 8; ++c) bad += a[i * Cd + c] != b[i * Cd + c];
+    if (bad) atomicAdd(&bad_by_lane[i & 63], (unsigned long long)bad);
+}
+
+struct F3State { uint16_t *x4, *w, *y, *yref; float *bias; unsigned long long *bad; hipStream_t s; int B, H, W, Ho, Wo, Cd; };
+static F3State g_f3;
+
+template <int V> static void f3_launch(uint16_t *y)
+{
+    const long long total = (long long)g_f3.B * g_f3.Ho * g_f3.Wo;
+    hipLaunchKernelGGL(victim_f3<V>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_f3.s, g_f3.x4, g_f3.w, g_f3.bias, y,
+                       g_f3.B, g_f3.H, g_f3.W, g_f3.Ho, g_f3.Wo, g_f3.Cd);
+}
+
+// reference run: call BEFORE any disturber is started
+extern "C" __attribute__((visibility("default"))) int hazard_f3_init(void)
+{
+    F3State &f = g_f3;
+    f.B = 8; f.H = 640; f.W = 640; f.Ho = 320; f.Wo = 320; f.Cd = 64;
+    const size_t nx = (size_t)f.B * f.H * f.W * 4, ny = (size_t)f.B * f.Ho * f.Wo * f.Cd;
+    CK(hipStreamCreateWithFlags(&f.s, hipStreamNonBlocking));
+    CK(hipMalloc(&f.x4, nx * 2)); CK(hipMalloc(&f.w, 288 * 2)); CK(hipMalloc(&f.bias, 8 * 4));
+    CK(hipMalloc(&f.y, ny * 2)); CK(hipMalloc(&f.yref, ny * 2)); CK(hipMalloc(&f.bad, 64 * 8));
+    std::vector<uint16_t> hx(nx), hw(288);
+    uint32_t r = 12345u;
+    for (auto &v : hx) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x4000u + ((r >> 20) & 0x3ffu)); } // bf16 in [2, 4)
+    for (auto &v : hw) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x3c00u + ((r >> 20) & 0x3ffu) + ((r >> 31) << 15)); }
+    float hb[8] = {0.1f, -0.2f, 0.3f, 0.05f, -0.4f, 0.2f, 0.0f, 0.15f};
+    CK(hipMemcpy(f.x4, hx.data(), nx * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(f.w, hw.data(), 288 * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(f.bias, hb, sizeof hb, hipMemcpyHostToDevice));
+    f3_launch<0>(f.yref);
+    CK(hipStreamSynchronize(f.s));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant, int launches, unsigned long long *out64)
+{
+    F3State &f = g_f3;
+    CK(hipMemsetAsync(f.bad, 0, 64 * 8, f.s));
+    const size_t npx = (size_t)f.B * f.Ho * f.Wo;
+    for (int i = 0; i < launches; ++i) {
+        if (variant == 0) f3_launch<0>(f.y);
+        else if (variant == 1) f3_launch<1>(f.y);
+        else if (variant == 2) f3_launch<2>(f.y);
+        else if (variant == 3) f3_launch<3>(f.y);
+        else if (variant == 4) f3_launch<4>(f.y);
+        else f3_launch<5>(f.y);
+        hipLaunchKernelGGL(hz_compare, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, f.s, f.y, f.yref, npx, f.Cd, f.bad);
+    }
+    CK(hipMemcpyAsync(out64, f.bad, 64 * 8, hipMemcpyDeviceToHost, f.s));
+    CK(hipStreamSynchronize(f.s));
+    return 0;
 }
 
 // ---- shared-library entry (tools/_hazard_with_conv.py): run one victim shape on its own stream while the caller
@@ -178,6 +397,41 @@ extern "C" __attribute__((visibility("default"))) int hazard_victim(int shape, i
     return 0;
 }
 
+static void launch_disturber(int dmode, int grid, int iters, const uint32_t *src, size_t nbytes, uint32_t *sink, hipStream_t sa)
+{
+    switch (dmode) {
+    case 0: hipLaunchKernelGGL(disturber<0>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 1: hipLaunchKernelGGL(disturber<1>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 2: hipLaunchKernelGGL(disturber<2>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 4: hipLaunchKernelGGL(disturber<3>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 5: hipLaunchKernelGGL(disturber<4>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 6: hipLaunchKernelGGL(disturber<5>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    case 7: hipLaunchKernelGGL(disturber<6>, dim3(grid), dim3(256), 32768, sa, src, nbytes, iters, sink); break;
+    default: break;
+    }
+}
+
+static void run_multi(int dmode, const uint32_t *src, size_t nbytes, uint32_t *sink, unsigned long long *d_bad, hipStream_t sa, hipStream_t sb)
+{
+    static uint32_t *d_g = nullptr;
+    if (!d_g) { CK(hipMalloc(&d_g, 4u << 20)); CK(hipMemset(d_g, 1, 4u << 20)); }
+    for (int with_vmem = 0; with_vmem < 2; ++with_vmem) {
+        CK(hipMemset(d_bad, 0, 64 * sizeof(unsigned long long)));
+        CK(hipDeviceSynchronize());
+        launch_disturber(dmode, 4096, 200, src, nbytes, sink, sa);
+        for (int rep = 0; rep < 4; ++rep) {
+            if (with_vmem) hipLaunchKernelGGL(victim_multi<1>, dim3(4096), dim3(256), 0, sb, 2000, d_bad, (const uint32_t *)d_g);
+            else hipLaunchKernelGGL(victim_multi<0>, dim3(4096), dim3(256), 0, sb, 2000, d_bad, (const uint32_t *)d_g);
+        }
+        CK(hipDeviceSynchronize());
+        unsigned long long h[64], tot = 0, q[4] = {0, 0, 0, 0};
+        CK(hipMemcpy(h, d_bad, sizeof h, hipMemcpyDeviceToHost));
+        for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
+        printf("  %-44s bad reads %10llu   by lane quarter [%llu %llu %llu %llu]\n",
+               with_vmem ? "8 broadcast reads in flight + a global load" : "8 broadcast reads in flight (4 b128 + 4 b96)", tot, q[0], q[1], q[2], q[3]);
+    }
+}
+
 int main()
 {
     const size_t nbytes = 256u << 20;
@@ -190,8 +444,10 @@ int main()
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    const char *dn[4] = {"LDS-DMA dwordx4 (buffer_load_dwordx4 lds)", "LDS-DMA dword (buffer_load_dword lds)", "global_load + ds_write_b128", "none"};
-    for (int dmode = 0; dmode < 4; ++dmode) {
+    const char *dn[8] = {"LDS-DMA dwordx4 (buffer_load_dwordx4 lds)", "LDS-DMA dword (buffer_load_dword lds)", "global_load + ds_write_b128", "none",
+                         "LDS-DMA dwordx4 + 16 fragment ds_read_b128 per step", "LDS-DMA dwordx4 + fragment reads + 32 MFMA per step",
+                         "fragment ds_read_b128 + 32 MFMA per step, no DMA", "32 MFMA per step on register operands only (no LDS traffic)"};
+    for (int dmode = 0; dmode < 8; ++dmode) {
         printf("disturber: %s\n", dn[dmode]);
         run_victim<0>("broadcast ds_read_b128", dmode, src, nbytes, sink, d_bad, sa, sb);
         run_victim<7>("two-address ds_read_b128 (lane>>5)", dmode, src, nbytes, sink, d_bad, sa, sb);
@@ -201,6 +457,27 @@ int main()
         run_victim<2>("broadcast ds_read_b64", dmode, src, nbytes, sink, d_bad, sa, sb);
         run_victim<6>("per-lane ds_read_b64", dmode, src, nbytes, sink, d_bad, sa, sb);
         run_victim<3>("broadcast ds_read_b32", dmode, src, nbytes, sink, d_bad, sa, sb);
+        run_multi(dmode, src, nbytes, sink, d_bad, sa, sb);
+        // the first-conv kernel variants (hazard_f3_*), same synthetic disturbers
+        if (dmode == 0) hazard_f3_init();
+        const char *fn[3] = {"first-conv kernel, compiler-chosen reads", "first-conv kernel, explicit broadcast b128", "first-conv kernel, explicit 2 x b64"};
+        const int fv[3] = {0, 3, 4};
+        for (int k = 0; k < 3; ++k) {
+            CK(hipDeviceSynchronize());
+            if (dmode == 0) hipLaunchKernelGGL(disturber<0>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 1) hipLaunchKernelGGL(disturber<1>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 2) hipLaunchKernelGGL(disturber<2>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 4) hipLaunchKernelGGL(disturber<3>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 5) hipLaunchKernelGGL(disturber<4>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 6) hipLaunchKernelGGL(disturber<5>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            else if (dmode == 7) hipLaunchKernelGGL(disturber<6>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
+            unsigned long long h[64];
+            hazard_f3_run(fv[k], 12, h);
+            CK(hipDeviceSynchronize());
+            unsigned long long tot = 0, q[4] = {0, 0, 0, 0};
+            for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
+            printf("  %-44s bad elements %8llu   by lane quarter [%llu %llu %llu %llu]\n", fn[k], tot, q[0], q[1], q[2], q[3]);
+        }
     }
     return 0;
 }
