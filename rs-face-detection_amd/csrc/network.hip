@@ -874,9 +874,15 @@ int Network::run_graphed(int B, hipStream_t s)
         return run_split(B, s);
     }
     hipGraph_t graph = nullptr;
+    // hipGraphLaunch of a graph with three parallel branches (main + two side chains) crashes inside this ROCm's
+    // hip::Graph::UpdateStreams when the process was started with GPU_MAX_HW_QUEUES < 3: capture a linear graph there
+    static const bool linear_graph = getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) < 3;
+    const bool ms_saved = multi_stream;
+    if (linear_graph) multi_stream = false;
     RFD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int st = run_split(B, s);
     const hipError_t e = hipStreamEndCapture(s, &graph);
+    multi_stream = ms_saved;
     if (st != RFD_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         use_graph = false; // capture unsupported here: stay eager
