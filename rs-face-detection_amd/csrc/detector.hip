@@ -705,6 +705,7 @@ int rfd_debug_set_concurrency(rfd_ctx *c, int multi_stream, int split_min_part, 
     c->net.multi_stream = multi_stream != 0;
     c->net.split_min_part = split_min_part;
     c->net.split_max_parts = split_max_parts;
+    c->net.tuned = false; // the stream choice depends on the number of parts
     c->net.use_graph = use_graph != 0;
     for (hipGraphExec_t &ge : c->net.graph_exec)
         if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }

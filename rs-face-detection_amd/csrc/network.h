@@ -115,7 +115,7 @@ struct Network {
     int run_split(int B, hipStream_t s); // whole pass; splits the batch over several streams when it pays
     int split_body(int B, int P, hipStream_t s);
     int tune_streams(int B, int P, hipStream_t s);
-    void assign_streams(int a, int b);
+    void assign_streams(int a, int b, int c);
     static constexpr int kPool = 8;
     hipStream_t pool[kPool] = {};
     bool tuned = false, tune = true;

@@ -399,7 +399,7 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
     RFD_HIP(hipMemset(d_w, 0, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMemset(d_b, 0, (g.b_total + g.a_total) * sizeof(float)));
     for (int i = 0; i < kPool; ++i) RFD_HIP(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
-    assign_streams(2, 5); // provisional (the measured-best order of one configuration); tune_streams() decides
+    assign_streams(2, 5, -1); // provisional (the measured-best order of one configuration); tune_streams() decides
     for (int hh = 0; hh < kMaxParts; ++hh) {
         for (int i = 0; i < 2; ++i) {
             RFD_HIP(hipEventCreateWithFlags(&ev_fork[hh][i], hipEventDisableTiming));
@@ -759,19 +759,21 @@ int Network::ensure_alt_heads()
     return RFD_OK;
 }
 
-// chain streams a, b for parts 0 / 1; the side streams (and parts 2, 3 when asked for) take the rest of the pool in order
-void Network::assign_streams(int a, int b)
+// chain streams a, b (, c) for parts 0 / 1 (/ 2); the side streams (and further parts) take the rest of the pool in order
+void Network::assign_streams(int a, int b, int c)
 {
     part_stream[0] = pool[a];
     part_stream[1] = pool[b];
+    if (c >= 0) part_stream[2] = pool[c];
     int k = 0;
     auto next = [&]() {
-        while (k == a || k == b) ++k;
+        while (k == a || k == b || k == c) ++k;
         return pool[k++ % kPool];
     };
-    for (int hh = 0; hh < 2; ++hh)
+    const int nchain = c >= 0 ? 3 : 2;
+    for (int hh = 0; hh < nchain; ++hh)
         for (int i = 0; i < 2; ++i) side[hh][i] = next();
-    for (int hh = 2; hh < kMaxParts; ++hh) {
+    for (int hh = nchain; hh < kMaxParts; ++hh) {
         part_stream[hh] = next();
         for (int i = 0; i < 2; ++i) side[hh][i] = next();
     }
@@ -806,8 +808,8 @@ int Network::tune_streams(int B, int P, hipStream_t s)
     RFD_HIP(hipEventCreate(&e0));
     RFD_HIP(hipEventCreate(&e1));
     int st = RFD_OK;
-    auto time_pair = [&](int a, int b, int reps, float *out) { // median of `reps` synchronous passes after one warm pass
-        assign_streams(a, b);
+    auto time_set = [&](int a, int b, int c, int reps, float *out) { // median of `reps` synchronous passes after one warm pass
+        assign_streams(a, b, c);
         std::vector<float> ts;
         for (int rep = 0; rep <= reps && st == RFD_OK; ++rep) {
             if (hipEventRecord(e0, s) != hipSuccess) st = RFD_ERR_HIP;
@@ -819,29 +821,38 @@ int Network::tune_streams(int B, int P, hipStream_t s)
         std::sort(ts.begin(), ts.end());
         *out = ts.empty() ? 1e30f : ts[ts.size() / 2];
     };
-    // coarse scan of all pairs (2 passes each), then the four best again with 9 passes each
-    std::vector<std::pair<float, std::pair<int, int>>> cand;
+    // coarse scan of all pairs (triples for three parts), 2 passes each, then the four best again with 9 passes each
+    struct Cand { float t; int a, b, c; };
+    std::vector<Cand> cand;
     for (int a = 0; a < kPool && st == RFD_OK; ++a)
         for (int b = a + 1; b < kPool && st == RFD_OK; ++b) {
-            float t;
-            time_pair(a, b, 2, &t);
-            cand.push_back({t, {a, b}});
+            if (P == 2) {
+                float t;
+                time_set(a, b, -1, 2, &t);
+                cand.push_back({t, a, b, -1});
+            } else {
+                for (int c = b + 1; c < kPool && st == RFD_OK; ++c) {
+                    float t;
+                    time_set(a, b, c, 2, &t);
+                    cand.push_back({t, a, b, c});
+                }
+            }
         }
-    std::sort(cand.begin(), cand.end());
+    std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.t < y.t; });
     float best = 1e30f;
-    int ba = 2, bb = 5;
+    int ba = 2, bb = 5, bc = P == 3 ? 6 : -1;
     for (size_t i = 0; i < cand.size() && i < 4 && st == RFD_OK; ++i) {
         float t;
-        time_pair(cand[i].second.first, cand[i].second.second, 9, &t);
-        if (t < best) { best = t; ba = cand[i].second.first; bb = cand[i].second.second; }
+        time_set(cand[i].a, cand[i].b, cand[i].c, 9, &t);
+        if (t < best) { best = t; ba = cand[i].a; bb = cand[i].b; bc = cand[i].c; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     RFD_TRY(st);
-    assign_streams(ba, bb);
+    assign_streams(ba, bb, bc);
     tuned_ms = best;
     tuned_a = ba; tuned_b = bb;
-    if (getenv("RFD_STREAM_TUNE_VERBOSE")) fprintf(stderr, "[rfd] chain streams: pool[%d], pool[%d] (%.3f ms per split pass at B = %d)\n", ba, bb, best, B);
+    if (getenv("RFD_STREAM_TUNE_VERBOSE")) fprintf(stderr, "[rfd] chain streams: pool[%d], pool[%d], pool[%d] (%.3f ms per split pass at B = %d)\n", ba, bb, bc, best, B);
     return RFD_OK;
 }
 
@@ -853,7 +864,7 @@ int Network::run_split(int B, hipStream_t s)
     const int P = num_parts(B);
     co_running = 0;
     if (P <= 1) return run(B, s);
-    if (!tuned && tune && P == 2) {
+    if (!tuned && tune && (P == 2 || P == 3)) {
         tuned = true;
         if (getenv("RFD_STREAM_TUNE") && atoi(getenv("RFD_STREAM_TUNE")) == 0) return split_body(B, P, s);
         RFD_TRY(tune_streams(B, P, s));
