@@ -11,9 +11,12 @@
 //   * disturber = any kernel issuing v_mfma_f32_16x16x32_bf16: LDS-DMA + fragment reads + MFMA (the conv kernels'
 //     loop shape), fragment reads + MFMA without DMA, and MFMA on register operands with no LDS traffic at all;
 //     LDS-DMA or LDS traffic WITHOUT MFMA does not trigger it (the file name records the first, wrong suspicion);
+//   * still wrong with the global loads taken out of the victim's loop (pixels made from coordinates); 20 x FEWER wrong
+//     elements when every wave repeats its nine taps 32 times and keeps the last round -- the errors sit early in a
+//     wave's life, i.e. around workgroup launch / the table fill + barrier, not in steady state;
 //   * plain read-and-compare victims of every shape (broadcast / per-lane / fragment b128, b96, b64, b32, eight reads in
-//     flight, with a global load pending) stay clean under every disturber -- so what the first-conv kernel adds to
-//     "a broadcast ds_read_b128" is still not isolated.
+//     flight, with a global load pending, feeding v_mul_f32 / v_pk_mul_f32) stay clean under every disturber: those
+//     waves live for thousands of reads, which fits the previous point, but the mechanism is not isolated.
 // The product therefore keeps broadcast operands out of ds_read_b128: scalar loads for weight tables, 64-bit LDS reads
 // or v_readlane in sort / NMS (tests/test_concurrency_gpu.py guards the pipeline).  The conv kernels' own per-lane
 // fragment ds_read_b128 next to their own MFMAs are not affected (bit-identical results in every execution mode).
@@ -231,6 +234,7 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
     const int ho = (int)((i / Wo) % Ho);
     const int b = (int)(i / ((long long)Wo * Ho));
     float acc[8];
+    for (int life = 0; life < (VARIANT == 7 ? 32 : 1); ++life) { // 7: long-lived waves, the result of the last round is kept
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = bias[c];
 #pragma unroll
@@ -241,7 +245,13 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
         for (int kx = 0; kx < 3; ++kx) {
             const int wi = 2 * wo - 1 + kx;
             if ((unsigned)wi >= (unsigned)W) continue;
-            const uint2 p = reinterpret_cast<const uint2 *>(x4)[((long long)b * H + hi) * W + wi];
+            uint2 p;
+            if (VARIANT == 6) { // no global load in the loop: a pixel made from the coordinates (bf16 2.0 .. 3.98)
+                p.x = (0x4000u + (uint32_t)((hi * 7 + wi * 3) & 0x7f)) | ((0x4000u + (uint32_t)((hi + wi) & 0x7f)) << 16);
+                p.y = 0x4000u + (uint32_t)((hi * 5 + wi) & 0x7f);
+            } else {
+                p = reinterpret_cast<const uint2 *>(x4)[((long long)b * H + hi) * W + wi];
+            }
             const float r = bf16_bits_to_f32(p.x & 0xffffu), g = bf16_bits_to_f32(p.x >> 16), bl = bf16_bits_to_f32(p.y & 0xffffu);
             if (VARIANT >= 3) {
                 // 3: the tap's 8 weight vectors by explicit broadcast ds_read_b128, ALL landed (lgkmcnt(0)) before any
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
                     wv[0] = f4{l0.x, l0.y, h0.x, h0.y}; wv[1] = f4{l1.x, l1.y, h1.x, h1.y}; wv[2] = f4{l2.x, l2.y, h2.x, h2.y};
                     wv[3] = f4{l3.x, l3.y, h3.x, h3.y}; wv[4] = f4{l4.x, l4.y, h4.x, h4.y}; wv[5] = f4{l5.x, l5.y, h5.x, h5.y};
                     wv[6] = f4{l6.x, l6.y, h6.x, h6.y}; wv[7] = f4{l7.x, l7.y, h7.x, h7.y};
-                } else if (VARIANT == 3) {
+                } else if (VARIANT == 3 || VARIANT == 6 || VARIANT == 7) {
                     asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
                                  "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
                                  "s_waitcnt lgkmcnt(0)"
@@ -300,6 +310,8 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
                 }
             }
         }
+    }
+    if (VARIANT == 7) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
     }
     uint4 *dst = reinterpret_cast<uint4 *>(y + i * Cd);
     const uint2 lo = pack_bf16x4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
@@ -349,6 +361,15 @@ extern "C" __attribute__((visibility("default"))) int hazard_f3_init(void)
     return 0;
 }
 
+// reference for a variant whose arithmetic differs from variant 0 (6: synthetic pixels): run it once UNDISTURBED
+extern "C" __attribute__((visibility("default"))) int hazard_f3_reference(int variant)
+{
+    F3State &f = g_f3;
+    if (variant == 6) f3_launch<6>(f.yref); else f3_launch<0>(f.yref);
+    CK(hipStreamSynchronize(f.s));
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant, int launches, unsigned long long *out64)
 {
     F3State &f = g_f3;
@@ -360,7 +381,9 @@ extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant,
         else if (variant == 2) f3_launch<2>(f.y);
         else if (variant == 3) f3_launch<3>(f.y);
         else if (variant == 4) f3_launch<4>(f.y);
-        else f3_launch<5>(f.y);
+        else if (variant == 5) f3_launch<5>(f.y);
+        else if (variant == 6) f3_launch<6>(f.y);
+        else f3_launch<7>(f.y);
         hipLaunchKernelGGL(hz_compare, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, f.s, f.y, f.yref, npx, f.Cd, f.bad);
     }
     CK(hipMemcpyAsync(out64, f.bad, 64 * 8, hipMemcpyDeviceToHost, f.s));
@@ -395,6 +418,48 @@ extern "C" __attribute__((visibility("default"))) int hazard_victim(int shape, i
     CK(hipMemcpyAsync(out64, d_bad, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sb));
     CK(hipStreamSynchronize(sb));
     return 0;
+}
+
+// ---- does the consumer matter?  broadcast ds_read_b128 of FLOATS, all landed, then the loaded registers go through
+//      v_pk_mul_f32 (PK = 1: packed, on the 64-bit halves of the loaded tuple), v_mul_f32 (PK = 0) or straight into a
+//      compare (PK = 2); 8 reads per step at 144-byte records like the first-conv kernel ----
+template <int PK> __global__ void __launch_bounds__(256) victim_pk(int iters, unsigned long long *bad_by_lane)
+{
+    __shared__ __attribute__((aligned(16))) float tab[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) tab[i] = 1.0f + 0.5f * (float)i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    unsigned bad = 0;
+    const f2 two = {2.0f, 2.0f};
+    for (int it = 0; it < iters; ++it) {
+        const int off = (it & 3) * 4; // dwords: tap 0..3 of eight 36-dword records
+        f4 w[8];
+        asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
+                     "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                     : "v"((uint32_t)(uintptr_t)tab + (uint32_t)off * 4u) : "memory");
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int d = off + c * 36;
+            float r[4];
+            if (PK == 1) {
+                f2 lo = {w[c].x, w[c].y}, hi = {w[c].z, w[c].w}, plo, phi;
+                asm volatile("v_pk_mul_f32 %0, %2, %4\n v_pk_mul_f32 %1, %3, %4" : "=&v"(plo), "=&v"(phi) : "v"(lo), "v"(hi), "v"(two));
+                r[0] = plo.x; r[1] = plo.y; r[2] = phi.x; r[3] = phi.y;
+            } else if (PK == 0) {
+                asm volatile("v_mul_f32 %0, 2.0, %4\n v_mul_f32 %1, 2.0, %5\n v_mul_f32 %2, 2.0, %6\n v_mul_f32 %3, 2.0, %7"
+                             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(w[c].x), "v"(w[c].y), "v"(w[c].z), "v"(w[c].w));
+            } else {
+                r[0] = 2.0f * w[c].x; r[1] = 2.0f * w[c].y; r[2] = 2.0f * w[c].z; r[3] = 2.0f * w[c].w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad += r[k] != 2.0f * (1.0f + 0.5f * (float)(d + k));
+        }
+    }
+    if (bad) atomicAdd(&bad_by_lane[lane], (unsigned long long)bad);
 }
 
 static void launch_disturber(int dmode, int grid, int iters, const uint32_t *src, size_t nbytes, uint32_t *sink, hipStream_t sa)
@@ -458,12 +523,30 @@ int main()
         run_victim<6>("per-lane ds_read_b64", dmode, src, nbytes, sink, d_bad, sa, sb);
         run_victim<3>("broadcast ds_read_b32", dmode, src, nbytes, sink, d_bad, sa, sb);
         run_multi(dmode, src, nbytes, sink, d_bad, sa, sb);
+        for (int pk = 0; pk < 3; ++pk) {
+            CK(hipMemset(d_bad, 0, 64 * sizeof(unsigned long long)));
+            CK(hipDeviceSynchronize());
+            launch_disturber(dmode, 4096, 200, src, nbytes, sink, sa);
+            for (int rep = 0; rep < 4; ++rep) {
+                if (pk == 0) hipLaunchKernelGGL(victim_pk<0>, dim3(4096), dim3(256), 0, sb, 500, d_bad);
+                else if (pk == 1) hipLaunchKernelGGL(victim_pk<1>, dim3(4096), dim3(256), 0, sb, 500, d_bad);
+                else hipLaunchKernelGGL(victim_pk<2>, dim3(4096), dim3(256), 0, sb, 500, d_bad);
+            }
+            CK(hipDeviceSynchronize());
+            unsigned long long h[64], tot = 0, q[4] = {0, 0, 0, 0};
+            CK(hipMemcpy(h, d_bad, sizeof h, hipMemcpyDeviceToHost));
+            for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
+            static const char *pn[3] = {"8 broadcast b128 of floats -> v_mul_f32", "8 broadcast b128 of floats -> v_pk_mul_f32", "8 broadcast b128 of floats -> compiler math"};
+            printf("  %-44s bad values %9llu   by lane quarter [%llu %llu %llu %llu]\n", pn[pk], tot, q[0], q[1], q[2], q[3]);
+        }
         // the first-conv kernel variants (hazard_f3_*), same synthetic disturbers
         if (dmode == 0) hazard_f3_init();
-        const char *fn[3] = {"first-conv kernel, compiler-chosen reads", "first-conv kernel, explicit broadcast b128", "first-conv kernel, explicit 2 x b64"};
-        const int fv[3] = {0, 3, 4};
-        for (int k = 0; k < 3; ++k) {
+        const char *fn[5] = {"first-conv kernel, compiler-chosen reads", "first-conv kernel, explicit broadcast b128", "first-conv kernel, explicit 2 x b64",
+                             "explicit b128, no global loads in the loop", "explicit b128, long-lived waves (32 rounds)"};
+        const int fv[5] = {0, 3, 4, 6, 7};
+        for (int k = 0; k < 5; ++k) {
             CK(hipDeviceSynchronize());
+            hazard_f3_reference(fv[k]);
             if (dmode == 0) hipLaunchKernelGGL(disturber<0>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
             else if (dmode == 1) hipLaunchKernelGGL(disturber<1>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
             else if (dmode == 2) hipLaunchKernelGGL(disturber<2>, dim3(8192), dim3(256), 32768, sa, src, nbytes, 400, sink);
