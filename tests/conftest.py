@@ -26,5 +26,8 @@ def rfd():
     # The other order puts two HIP runtimes into one process, and whichever initialises second may find no device.
     import torch  # noqa: F401
     import rfd_hip
+    if not os.path.exists(rfd_hip.LIB_PATH):  # fresh checkout: the .so is git-ignored; hipcc cross-compiles without a GPU
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "rs-face-detection_amd", "build.sh")])
     rfd_hip.load_library()  # raises if librfd_hip.so is missing: no CPU fallback
     return rfd_hip
