@@ -60,3 +60,37 @@ def test_bn_fold_math_and_errors(rfd):
     bad["fpn_lat2_weight"] = bad["fpn_lat2_weight"][:, :512]
     with pytest.raises(ValueError):
         convert.import_unfolded(Null(), g, bad)
+
+
+def test_plan_for_mobilenet(rfd):
+    """MobileNet-0.25: every conv (first 3x3, depthwise, pointwise, FPN, SSH) carries a BN to fold, no pre-activation
+    affines; shapes are checked by a recording stand-in for the detector."""
+    from rfd_hip import convert
+    g = rfd.Graph(rfd.BACKBONE_MNET025, 640, 640)
+    plan = convert.layer_plan(g)
+    assert all(e["affine_bn"] is None for e in plan)
+    assert {e["kind"] for e in plan} == {"bn", "head"} and sum(e["kind"] == "head" for e in plan) == 3
+    rng = np.random.default_rng(0)
+    P = {}
+    for L, e in zip(g.layers, plan):
+        if e["kind"] == "head":
+            st = e["name"][4:]
+            for nm, co in (("cls", 4), ("bbox", 8), ("lmk", 20)):
+                P["head%s_%s_weight" % (st, nm)] = rng.normal(size=(co, L.cin, 1, 1)).astype(np.float32)
+                P["head%s_%s_bias" % (st, nm)] = rng.normal(size=co).astype(np.float32)
+        else:
+            P[e["name"] + "_weight"] = rng.normal(size=(L.cout, L.cin, L.kh, L.kw)).astype(np.float32)
+            for k in ("gamma", "beta", "mean", "var"):
+                P["%s_bn_%s" % (e["name"], k)] = rng.uniform(0.5, 1.5, L.cout).astype(np.float32)
+    seen = []
+
+    class Rec:
+        def set_layer(self, i, w, b):
+            L = g.layers[i]
+            assert w.shape == (L.cout, L.kh, L.kw, L.cin) and b.shape == (L.cout,)
+            seen.append(i)
+
+        def set_affine(self, i, s, t):
+            raise AssertionError("no affine expected")
+
+    assert convert.import_unfolded(Rec(), g, P) == set(P) and seen == list(range(g.num_layers))
