@@ -51,7 +51,6 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16,
                                              voffset, soffset, 0, 0);
 }
-constexpr bool kSetPrio = true; // raise the wave's issue priority over its MFMA clusters
 constexpr uint32_t kOob = 0xfffffff0u; // >= any num_records: reads as zeros, touches no memory
 
 // residual prefetch (independent of the GEMM): 16 bytes = the lane's 8 channels of pixel (j)
@@ -341,13 +340,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                     bfr[j] = v;
                 }
             }
-            if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            if (kSetPrio) __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -495,14 +492,12 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
                     if ((kx == 0 && col_first[j]) || (kx == 2 && col_last[j])) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     bfr[j] = v;
                 }
-                if (kSetPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
+    #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                if (kSetPrio) __builtin_amdgcn_s_setprio(0);
-            }
+                }
         }
         xslot ^= 1;
         ky = nky; kc = nkc;

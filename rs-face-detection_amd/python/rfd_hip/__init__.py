@@ -110,7 +110,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RFD_HIP_LIB") or LIB_PATH  # RFD_HIP_LIB: A/B runs of two builds on one box
     if not os.path.exists(p):
         raise ImportError("librfd_hip.so not found at %s -- build it with "
                           "rs-face-detection_amd/build.sh (there is no CPU fallback)" % p)
