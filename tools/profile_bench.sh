@@ -8,12 +8,13 @@ export RFD_STREAM_TUNE=0   # the one-off stream tuner would add ~120 extra passe
 export RFD_BENCH_ASYNC=1   # calls ordered on one stream, so that a pass can be delimited in the trace
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $O/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $O/bench_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $O/bench_mfma.log 2>&1
 python3 $R/tools/rocpd_summary.py mfma $(find $O/mfma -name "*_results.db" | head -1) $O/mfma_util.json
 python3 $R/tools/rocpd_summary.py stats $(find $O/stats -name "*_results.db" | head -1) $O/kernel_stats.csv $O/network_busy.json
 python3 $R/tools/rocpd_summary.py pmc $(find $O/fetch -name "*_results.db" | head -1) $(find $O/write -name "*_results.db" | head -1) $O/hbm_traffic.json
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null || true
 grep -h '"metric"' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
 rm -rf $O/stats $O/fetch $O/write $O/mfma $O/bench_mfma.log $O/bench_fetch.log $O/bench_write.log $O/bench_under_rocprof.log
