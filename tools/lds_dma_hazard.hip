@@ -22,7 +22,7 @@
 // fragment ds_read_b128 next to their own MFMAs are not affected (bit-identical results in every execution mode).
 //
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o lds_dma_hazard tools/lds_dma_hazard.hip && ./lds_dma_hazard
-//   hipcc ... -shared -fPIC -o tools/bin/liblds_dma_hazard.so tools/lds_dma_hazard.hip   (tools/_hazard_with_conv.py:
+//   hipcc ... -shared -fPIC -o tools/bin/liblds_dma_hazard.so tools/lds_dma_hazard.hip   (tools/hazard_with_conv.py:
 //   the same victims with the real conv kernels of librfd_hip.so as the disturber)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -391,7 +391,7 @@ extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant,
     return 0;
 }
 
-// ---- shared-library entry (tools/_hazard_with_conv.py): run one victim shape on its own stream while the caller
+// ---- shared-library entry (tools/hazard_with_conv.py): run one victim shape on its own stream while the caller
 //      keeps real conv kernels of librfd_hip.so in flight from another thread ----
 extern "C" __attribute__((visibility("default"))) int hazard_victim(int shape, int launches, int iters, unsigned long long *out64)
 {
