@@ -42,7 +42,8 @@ typedef enum rfd_status {
     RFD_ERR_HIP = -3,         /* a HIP call or kernel failed (reference: Triton RPC failure, face_detection.rs:282) */
     RFD_ERR_CAPACITY = -4,    /* batch / frame / detections exceed the configured capacity */
     RFD_ERR_STATE = -5,       /* weights not initialised (reference: empty model config, face_detection.rs:239) */
-    RFD_ERR_IO = -6           /* weight file could not be read / written */
+    RFD_ERR_IO = -6,          /* weight file could not be read / written */
+    RFD_ERR_COMM = -7         /* librccl missing, or an RCCL call failed (multi-GPU gather) */
 } rfd_status;
 
 typedef enum rfd_backbone {
@@ -201,6 +202,24 @@ RFD_API int rfd_sync(rfd_ctx *ctx);
  * that a following collective (RCCL gather of the detection slabs) is stream-ordered behind the
  * detector without a host synchronisation. */
 RFD_API int rfd_set_stream(rfd_ctx *ctx, void *hip_stream);
+
+/* ---- multi-GPU (the reference is single-device, one image per call: face_detection.rs:220).
+ *      Frames shard image-parallel, one process (or thread) and one context per GPU, weights replicated; the only
+ *      exchange step is the gather of the per-rank detection slabs, an RCCL all-gather over xGMI enqueued on the
+ *      context's stream, i.e. stream-ordered behind the rank's NMS with no host synchronisation.
+ *        rank 0:      rfd_comm_get_unique_id(id)          -> send the RFD_COMM_ID_BYTES bytes to every rank out of band
+ *        every rank:  rfd_comm_init(ctx, id, rank, world) (collective: returns when all ranks have joined)
+ *        per batch:   rfd_detect_batch_device(ctx, ..., &local, async) ; rfd_gather_detections(ctx, &local, n_local, &all)
+ *      `local` and `all` are DEVICE slabs; every rank passes the same n_local (a short tail rank pads with count = 0) and
+ *      `all` holds world * n_local frames, rank-major = the original frame order of a contiguous split:
+ *      boxes [world*n_local][max_det][5], landmarks [..][max_det][10], count [..], total [..] (total may be NULL in both).
+ *      librccl is loaded on first use (dlopen; RFD_RCCL_LIB overrides the name): single-GPU users never need it. ---- */
+#define RFD_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+RFD_API int rfd_comm_get_unique_id(void *id /* RFD_COMM_ID_BYTES bytes, host */);
+RFD_API int rfd_comm_init(rfd_ctx *ctx, const void *unique_id, int rank, int world);
+RFD_API int rfd_comm_info(const rfd_ctx *ctx, int *rank, int *world); /* world = 0: no communicator */
+RFD_API int rfd_gather_detections(rfd_ctx *ctx, const rfd_dets *local, int n_local, rfd_dets *all);
+RFD_API int rfd_comm_destroy(rfd_ctx *ctx);
 
 /* ---- stage-level entry points (parity tests; each mirrors one reference stage) ---- */
 

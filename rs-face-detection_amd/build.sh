@@ -15,7 +15,7 @@ for f in kernels_pre kernels_post kernels_conv network detector; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/librfd_hip.so" "$OBJ"/kernels_pre.o "$OBJ"/kernels_post.o "$OBJ"/kernels_conv.o "$OBJ"/network.o "$OBJ"/detector.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/librfd_hip.so" "$OBJ"/kernels_pre.o "$OBJ"/kernels_post.o "$OBJ"/kernels_conv.o "$OBJ"/network.o "$OBJ"/detector.o -ldl
 echo "built $HERE/librfd_hip.so"
 # compiled-language user of the C ABI through include/rfd.hpp (tests/test_cpp_facade_*.py)
 g++ -std=c++17 -O2 -Wall -I"$HERE/../include" "$HERE/../tests/cpp/facade_demo.cpp" -o "$OBJ/facade_demo" -L"$HERE" -lrfd_hip -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,"$HERE" -Wl,-rpath,/opt/rocm/lib

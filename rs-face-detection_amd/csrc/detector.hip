@@ -2,7 +2,9 @@
 // `RetinaFaceDetection` (src/pipeline/module/face_detection.rs:19-513) driving the HIP kernels, and
 // the C ABI of include/rfd.h on top of it.  (The reference's host language, Rust, has no toolchain
 // in this image; INTEGRATION.md shows the `extern "C"` facade that keeps its `call` signature.)
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -77,6 +79,71 @@ static void letterbox(int img_h, int img_w, int size_w, int size_h, PreImage *pi
     }
 }
 
+// ---- RCCL, bound at run time: single-GPU users (and the CPU-side ABI tests) never load the 500 MB library.  Only the
+//      handful of entry points the gather needs; types restated from rccl.h (ABI-stable since NCCL 2.0). ----
+struct Rccl {
+    typedef struct { char internal[RFD_COMM_ID_BYTES]; } UniqueId;
+    typedef void *Comm;
+    enum { kInt32 = 2 }; // ncclInt32
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *handle = nullptr;
+    bool ok = false;
+};
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.ok) return RFD_OK;
+    const char *env = getenv("RFD_RCCL_LIB");
+    void *h = nullptr;
+    if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    // a copy some other component of the process already loaded (e.g. the one PyTorch bundles) comes first: one RCCL per process
+    static const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (int pass = 0; pass < 2 && !h; ++pass)
+        for (const char *nm : names) {
+            h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (h) break;
+        }
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        set_error("librccl could not be loaded (%s); set RFD_RCCL_LIB", dlerror());
+        return RFD_ERR_COMM;
+    }
+    Rccl r;
+    r.handle = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        set_error("the loaded librccl lacks a required entry point");
+        return RFD_ERR_COMM;
+    }
+    r.ok = true;
+    g_rccl = r;
+    return RFD_OK;
+}
+
+#define RFD_RCCL(expr)                                                                                      \
+    do {                                                                                                    \
+        const int _r = (expr);                                                                              \
+        if (_r != 0) {                                                                                      \
+            ::rfd::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+            return RFD_ERR_COMM;                                                                            \
+        }                                                                                                   \
+    } while (0)
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -138,6 +205,14 @@ struct rfd_ctx {
     hipEvent_t ov_chain_done[2][2] = {}, ov_post_done[2] = {}, ov_desc = nullptr;
     bool ov_post_valid[2] = {false, false};
     int ov_parity = 0;
+    // batch size of the previous call if it ran in the overlap mode, else -1: the part boundary (n+1)/2 and with it the
+    // workspace / input slices of the two chains depend on n, and every other entry point runs the network on the
+    // caller's stream, so a chain may start under the previous call only when that call had the same shape
+    int ov_last_n = -1;
+    hipEvent_t ov_resync = nullptr;
+    // multi-GPU: RCCL communicator of this rank (rfd_comm_init)
+    Rccl::Comm comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
     rfd_stats stats;
     float conv_ms = 0.f;
     double conv_flops = 0.0;
@@ -312,6 +387,7 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
     const size_t B = (size_t)c->cfg.max_batch_size;
     if (!c->ov_desc) {
         RFD_HIP(hipEventCreateWithFlags(&c->ov_desc, hipEventDisableTiming));
+        RFD_HIP(hipEventCreateWithFlags(&c->ov_resync, hipEventDisableTiming));
         for (int a = 0; a < 2; ++a) {
             RFD_HIP(hipEventCreateWithFlags(&c->ov_post_done[a], hipEventDisableTiming));
             for (int b = 0; b < 2; ++b) RFD_HIP(hipEventCreateWithFlags(&c->ov_chain_done[a][b], hipEventDisableTiming));
@@ -334,6 +410,14 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         pis[i].stride = (long long)imgs[i].stride;
     }
     hipStream_t st[2] = {net.part_stream[0], net.part_stream[1]};
+    if (c->ov_last_n != n) {
+        // Different slices than the previous call's chains (another batch size), or the previous call ran on the caller's
+        // stream (any other entry point): both chains start behind everything enqueued so far.  The caller's stream has
+        // already waited for every earlier chain (post_network of each overlapped call sits behind ov_chain_done).
+        RFD_HIP(hipEventRecord(c->ov_resync, c->stream));
+        for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_resync, 0));
+    }
+    c->ov_last_n = n;
     if (c->ov_post_valid[par])
         for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_post_done[par], 0));
     RFD_HIP(hipMemcpyAsync(c->ov_imgs[par].p, pis, n * sizeof(PreImage), hipMemcpyHostToDevice, st[0]));
@@ -358,7 +442,7 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         if (status == RFD_OK && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
     }
     net.co_running = 0;
-    if (status != RFD_OK) { net.head_parity = 0; return status; }
+    if (status != RFD_OK) { net.head_parity = 0; c->ov_last_n = -1; return status; }
     for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(c->stream, c->ov_chain_done[par][p], 0));
     DecodeParams dp;
     fill_decode_params(c, dp);
@@ -383,6 +467,7 @@ int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on
         return detect_overlapped(c, imgs, n, out);
     }
     RFD_HIP(hipSetDevice(c->cfg.device_id));
+    c->ov_last_n = -1;
     std::vector<float> scales;
     RFD_HIP(hipEventRecord(c->ev[0], c->stream));
     RFD_TRY(stage_frames(c, imgs, n, frames_on_device, scales));
@@ -508,6 +593,7 @@ void rfd_destroy(rfd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
     (void)hipDeviceSynchronize(); // part / side / copy streams included
+    if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->net_created) c->net.destroy();
     DevBuf *bufs[] = {&c->staging, &c->imgs, &c->in4, &c->rows, &c->keys, &c->sorted_keys, &c->sorted_boxes,
                       &c->count, &c->det_scale, &c->out_boxes, &c->out_lmk, &c->out_count, &c->out_total,
@@ -539,6 +625,7 @@ void rfd_destroy(rfd_ctx *c)
             if (c->ov_chain_done[a][b]) (void)hipEventDestroy(c->ov_chain_done[a][b]);
     }
     if (c->ov_desc) (void)hipEventDestroy(c->ov_desc);
+    if (c->ov_resync) (void)hipEventDestroy(c->ov_resync);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -685,6 +772,7 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
     RFD_CHECK_ARG(tensor_id >= 0 && tensor_id < (int)c->net.g.tensors.size(), "tensor id out of range");
     RFD_CHECK_ARG(n >= 1 && n <= c->cfg.max_batch_size, "batch out of range");
     const size_t bytes = c->net.g.tensors[tensor_id].bytes_per_image() * (size_t)n;
+    c->ov_last_n = -1;
     if (write) RFD_HIP(hipMemcpyAsync(c->net.tensor_ptr(tensor_id), host, bytes, hipMemcpyHostToDevice, c->stream));
     else RFD_HIP(hipMemcpyAsync(host, c->net.tensor_ptr(tensor_id), bytes, hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
@@ -716,6 +804,7 @@ int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
     RFD_CHECK_ARG(c, "ctx is null");
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     RFD_TRY(c->ensure_network());
+    c->ov_last_n = -1;
     RFD_TRY(c->net.run(n, c->stream, first_op, last_op));
     RFD_HIP(hipStreamSynchronize(c->stream));
     if (c->net.profiling) RFD_TRY(c->net.collect_profile());
@@ -861,6 +950,75 @@ int rfd_sync(rfd_ctx *c)
     return RFD_OK;
 }
 
+// ---- multi-GPU gather ----
+int rfd_comm_get_unique_id(void *id)
+{
+    RFD_CHECK_ARG(id != nullptr, "id is null");
+    RFD_TRY(rccl_load());
+    Rccl::UniqueId u;
+    RFD_RCCL(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return RFD_OK;
+}
+
+int rfd_comm_init(rfd_ctx *c, const void *unique_id, int rank, int world)
+{
+    RFD_CHECK_ARG(c && unique_id, "null argument");
+    RFD_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "rank / world out of range");
+    if (c->comm) { set_error("the context already has a communicator: call rfd_comm_destroy first"); return RFD_ERR_STATE; }
+    RFD_TRY(rccl_load());
+    RFD_HIP(hipSetDevice(c->cfg.device_id)); // the communicator binds to the calling thread's current device
+    Rccl::UniqueId u;
+    memcpy(&u, unique_id, sizeof u);
+    Rccl::Comm comm = nullptr;
+    RFD_RCCL(g_rccl.CommInitRank(&comm, world, u, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return RFD_OK;
+}
+
+int rfd_comm_info(const rfd_ctx *c, int *rank, int *world)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (world) *world = c->comm ? c->comm_world : 0;
+    return RFD_OK;
+}
+
+int rfd_gather_detections(rfd_ctx *c, const rfd_dets *local, int n_local, rfd_dets *all)
+{
+    RFD_CHECK_ARG(c && local && all, "null argument");
+    RFD_CHECK_ARG(local->boxes && local->landmarks && local->count && all->boxes && all->landmarks && all->count,
+                  "slab pointers are null");
+    RFD_CHECK_ARG((local->total != nullptr) == (all->total != nullptr), "total must be given in both slabs or in neither");
+    if (!c->comm) { set_error("no communicator: call rfd_comm_init first"); return RFD_ERR_STATE; }
+    if (n_local < 1 || n_local > c->cfg.max_batch_size) { set_error("n_local %d exceeds max_batch_size %d", n_local, c->cfg.max_batch_size); return RFD_ERR_CAPACITY; }
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    const size_t MD = (size_t)c->cfg.max_det, n = (size_t)n_local;
+    // four arrays, one fused collective; everything moves as 32-bit words (floats are not interpreted)
+    RFD_RCCL(g_rccl.GroupStart());
+    int r = g_rccl.AllGather(local->boxes, all->boxes, n * MD * 5, Rccl::kInt32, c->comm, c->stream);
+    if (r == 0) r = g_rccl.AllGather(local->landmarks, all->landmarks, n * MD * 10, Rccl::kInt32, c->comm, c->stream);
+    if (r == 0) r = g_rccl.AllGather(local->count, all->count, n, Rccl::kInt32, c->comm, c->stream);
+    if (r == 0 && local->total) r = g_rccl.AllGather(local->total, all->total, n, Rccl::kInt32, c->comm, c->stream);
+    const int e = g_rccl.GroupEnd();
+    if (r != 0 || e != 0) {
+        set_error("ncclAllGather of the detection slabs failed: %s", g_rccl.GetErrorString(r != 0 ? r : e));
+        return RFD_ERR_COMM;
+    }
+    return RFD_OK;
+}
+
+int rfd_comm_destroy(rfd_ctx *c)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    if (!c->comm) return RFD_OK;
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_RCCL(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_world = 0; c->comm_rank = 0;
+    return RFD_OK;
+}
+
 // ---- pipelined host entry ----
 int rfd_host_alloc(size_t bytes, void **ptr)
 {
@@ -884,6 +1042,7 @@ int rfd_submit_batch(rfd_ctx *c, const rfd_image *imgs, int n)
     }
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     RFD_TRY(c->ensure_network());
+    c->ov_last_n = -1;
     const size_t B = (size_t)c->cfg.max_batch_size, MD = (size_t)c->cfg.max_det;
     rfd_ctx::PipeSlot &ps = c->pipe[c->pipe_head];
     if (!c->copy_stream) RFD_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -1002,6 +1161,7 @@ int rfd_forward(rfd_ctx *c, const float *tensor, int n, float *const heads[9])
     if (n < 1 || n > c->cfg.max_batch_size) { set_error("batch %d exceeds max_batch_size %d", n, c->cfg.max_batch_size); return RFD_ERR_CAPACITY; }
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     RFD_TRY(c->ensure_network());
+    c->ov_last_n = -1;
     const size_t plane = (size_t)c->cfg.image_h * c->cfg.image_w;
     RFD_TRY(c->scratch[1].reserve(n * plane * 3 * sizeof(float)));
     RFD_HIP(hipMemcpyAsync(c->scratch[1].p, tensor, n * plane * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));

@@ -512,11 +512,8 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
     const int grid = ceil_div(M, 128) * (p.Cout / BN);
     const size_t lds = (size_t)(2 * 160 + 2 * BN) * 64 * sizeof(bf16_t);
     auto kern = conv3x3_kx_kernel<BN, WAVES_M, WAVES_N>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -710,11 +707,8 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     }
     const int M = p.B * p.H * p.W;
     const size_t lds = (size_t)(128 * 64 + 256 * 64 + 4 * 128 * 64 + 4 * 64 * 64) * sizeof(bf16_t); // 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_b2b_s1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv_b2b_s1_kernel), (int)lds));
     hipLaunchKernelGGL(conv_b2b_s1_kernel, dim3(ceil_div(M, 128)), dim3(512), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -731,12 +725,8 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
     // single K step: one slot each, more workgroups per CU
     const size_t lds = (nk > 1 ? full : (size_t)(BM + BN) * 64 * sizeof(bf16_t)) + aff_bytes;
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NSX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(full + 16384)));
-        attr_set = true;
-    }
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)(full + 16384)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;

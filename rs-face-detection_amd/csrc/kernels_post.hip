@@ -524,14 +524,9 @@ int launch_nms(NmsParams p, int n_images, hipStream_t s)
         set_error("NMS bitmap for %d anchors does not fit LDS", p.total_anchors);
         return RFD_ERR_CAPACITY;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static DynLdsOnce once_stream, once_reg;
+    RFD_TRY(once_stream.ensure(reinterpret_cast<const void *>(nms_kernel<false>), 160 * 1024));
+    RFD_TRY(once_reg.ensure(reinterpret_cast<const void *>(nms_kernel<true>), 160 * 1024));
     if (reg) hipLaunchKernelGGL(nms_kernel<true>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     else hipLaunchKernelGGL(nms_kernel<false>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     RFD_HIP(hipGetLastError());

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <string>
 
 #include "../../include/rfd.h"
@@ -73,5 +74,23 @@ constexpr int kA = 2;                             // anchors per position (_num_
 constexpr int kDetRow = 16;                       // floats per decoded row: box4 score1 lmk10 pad1
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: one flag per (kernel, device),
+// read and set atomically (the attribute call itself is idempotent, so two threads racing through it is harmless).
+// Usage: `static DynLdsOnce once; RFD_TRY(once.ensure(kernel_ptr, bytes));` next to the launch.
+struct DynLdsOnce {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<int> bytes_set[kMaxDevices] = {};
+    int ensure(const void *kernel, int bytes)
+    {
+        int dev = 0;
+        RFD_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= kMaxDevices) { set_error("device ordinal %d out of range", dev); return RFD_ERR_NO_DEVICE; }
+        if (bytes_set[dev].load(std::memory_order_acquire) >= bytes) return RFD_OK;
+        RFD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        bytes_set[dev].store(bytes, std::memory_order_release);
+        return RFD_OK;
+    }
+};
 
 } // namespace rfd

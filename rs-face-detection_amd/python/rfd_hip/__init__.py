@@ -19,6 +19,8 @@ RFD_ERR_HIP = -3
 RFD_ERR_CAPACITY = -4
 RFD_ERR_STATE = -5
 RFD_ERR_IO = -6
+RFD_ERR_COMM = -7
+COMM_ID_BYTES = 128
 
 BACKBONE_R50 = 0
 BACKBONE_MNET025 = 1
@@ -100,6 +102,7 @@ API_SYMBOLS = [
     "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
     "rfd_alignment_config_default", "rfd_align_faces", "rfd_detect_select_align_batch",
     "rfd_host_alloc", "rfd_host_free", "rfd_submit_batch", "rfd_collect_batch",
+    "rfd_comm_get_unique_id", "rfd_comm_init", "rfd_comm_info", "rfd_gather_detections", "rfd_comm_destroy",
 ]
 
 _lib = None
@@ -169,6 +172,11 @@ def load_library(path=None):
     L.rfd_host_free.argtypes = [vp]
     L.rfd_submit_batch.argtypes = [vp, C.POINTER(rfd_image), ci]
     L.rfd_collect_batch.argtypes = [vp, C.POINTER(rfd_dets), C.POINTER(ci)]
+    L.rfd_comm_get_unique_id.argtypes = [vp]
+    L.rfd_comm_init.argtypes = [vp, vp, ci, ci]
+    L.rfd_comm_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.rfd_gather_detections.argtypes = [vp, C.POINTER(rfd_dets), ci, C.POINTER(rfd_dets)]
+    L.rfd_comm_destroy.argtypes = [vp]
     L.rfd_alignment_config_default.argtypes = [C.POINTER(rfd_alignment_config)]
     L.rfd_alignment_config_default.restype = None
     L.rfd_align_faces.argtypes = [vp, C.POINTER(rfd_image), ci, vp, vp, vp, vp, vp, vp]
@@ -386,6 +394,33 @@ class RetinaFaceDetection:
 
     def sync(self):
         _check(self._L.rfd_sync(self._ctx))
+
+    # ---- multi-GPU: RCCL all-gather of the detection slabs behind the C ABI ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: 128 opaque bytes to hand to every rank (any transport)."""
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _check(load_library().rfd_comm_get_unique_id(C.addressof(buf)))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._L.rfd_comm_init(self._ctx, C.addressof(buf), int(rank), int(world)))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        _check(self._L.rfd_comm_info(self._ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def gather_detections(self, local_ptrs, n_local, all_ptrs):
+        """local_ptrs / all_ptrs: (boxes, landmarks, count, total) DEVICE addresses; enqueued on the context's stream."""
+        a = rfd_dets(*local_ptrs)
+        b = rfd_dets(*all_ptrs)
+        _check(self._L.rfd_gather_detections(self._ctx, C.byref(a), int(n_local), C.byref(b)))
+
+    def comm_destroy(self):
+        _check(self._L.rfd_comm_destroy(self._ctx))
 
     def set_stream(self, hip_stream):
         """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None restores."""

@@ -82,3 +82,40 @@ def unpack_gathered(slab, gathered):
     for r in range(gathered.shape[0]):
         res += slab.unpack(gathered[r])
     return res
+
+
+class GatheredSlabs:
+    """Destination of rfd_gather_detections: `world` slabs of `batch` frames each, as four rank-major arrays
+    (boxes [world*batch][max_det][5] | landmarks | count | total) in one device buffer."""
+
+    def __init__(self, world, batch, max_det, device):
+        self.world, self.batch, self.max_det = world, batch, max_det
+        n = world * batch
+        self.n_boxes, self.n_lmk = n * max_det * 5, n * max_det * 10
+        self.buf = torch.zeros(self.n_boxes + self.n_lmk + 2 * n, dtype=torch.int32, device=device)
+
+    def pointers(self):
+        base = self.buf.data_ptr()
+        o = 4 * self.n_boxes
+        n = self.world * self.batch
+        return base, base + o, base + o + 4 * self.n_lmk, base + o + 4 * self.n_lmk + 4 * n
+
+    def unpack(self):
+        n = self.world * self.batch
+        b = self.buf.cpu()
+        bx = b[:self.n_boxes].view(torch.float32).view(n, self.max_det, 5).numpy()
+        lm = b[self.n_boxes:self.n_boxes + self.n_lmk].view(torch.float32).view(n, self.max_det, 5, 2).numpy()
+        ct = b[self.n_boxes + self.n_lmk:self.n_boxes + self.n_lmk + n].numpy()
+        tt = b[self.n_boxes + self.n_lmk + n:].numpy()
+        return [(bx[i, :ct[i]].copy(), lm[i, :ct[i]].copy()) for i in range(n)], tt.copy()
+
+
+def init_comm(det, group=None):
+    """Build the detector's own RCCL communicator (C ABI: rfd_comm_init) for the ranks of a torch.distributed group:
+    rank 0 draws the unique id, torch.distributed only carries its 128 bytes."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [det.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    det.comm_init(box[0], rank, world)
+    return rank, world

@@ -49,6 +49,15 @@ def _worker(rank, world, port, total, max_det, q):
     slab.fill_from(_dets_for(range(lo, hi)))
     gathered, _ = parallel.gather_detections(slab)
     res = parallel.unpack_gathered(slab, gathered)
+    # the layout of the C ABI's gather (rfd_gather_detections: four all-gathers, each array rank-major) with gloo
+    # standing in for ncclAllGather: GatheredSlabs.unpack must give the same rows
+    gs = parallel.GatheredSlabs(world, per, max_det, "cpu")
+    nb, nl, n = gs.n_boxes, gs.n_lmk, world * per
+    for dst, src in ((gs.buf[:nb], slab.buf[:slab.n_boxes]), (gs.buf[nb:nb + nl], slab.buf[slab.n_boxes:slab.n_boxes + slab.n_lmk]),
+                     (gs.buf[nb + nl:nb + nl + n], slab.count()), (gs.buf[nb + nl + n:], slab.total())):
+        dist.all_gather_into_tensor(dst, src.contiguous())
+    res2, tot2 = gs.unpack()
+    assert len(res2) == len(res) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(res, res2))
     if rank == 0:
         q.put([(d.tolist(), k.tolist()) for d, k in res])
     dist.barrier()
@@ -100,3 +109,27 @@ def test_gather_world_size_2_matches_single_process(total):
         assert np.array_equal(np.array(res[i][1], np.float32).reshape(-1, 5, 2), k[:max_det])
     for i in range(total, per * world):
         assert res[i][0] == []
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start N rank processes itself (the driver's multi-GPU
+    command), relay rank 0's single JSON line and return the children's status.  Rehearsed on CPU: RFD_BENCH_DRYRUN makes
+    every rank stop after the rendezvous + one gloo all-reduce, before any GPU call."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["RFD_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 2, "rank_sum": 3, "steps": 3, "warmup": 1}
+    # a failing rank makes the launcher fail
+    env["RFD_BENCH_DRYRUN_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0

@@ -1,5 +1,7 @@
 """rfd_submit_batch / rfd_collect_batch: two batches in flight, H2D on its own stream.
-Results must equal the synchronous rfd_detect_batch on the same frames, in submission order."""
+Results are checked against the ORACLE (decode / sort / NMS / rescale of the head tensors of the same frames:
+identical kept-anchor sequences, coordinates within 1e-4) and must equal the synchronous rfd_detect_batch on the same
+frames, in submission order."""
 import numpy as np
 import pytest
 
@@ -44,6 +46,42 @@ def test_pipelined_equals_synchronous(rfd, pinned):
         assert _same(g, w)
     # the synchronous entry still works afterwards
     assert _same(det.call_batch(batches[1]), want[1])
+    det.close()
+
+
+@pytest.mark.parametrize("backbone,n", [("r50", 8), ("mnet025", 4)])
+def test_pipelined_matches_oracle(rfd, oracle, backbone, n):
+    """collect() against the oracle's post-network path (face_detection.rs:319-493) on the device's head tensors of the
+    same frames -- R50 at n = 8 runs the pass as two 4-image chains (the split path), MobileNet as one graph."""
+    bb = rfd.BACKBONE_R50 if backbone == "r50" else rfd.BACKBONE_MNET025
+    det = rfd.RetinaFaceDetection(max_batch_size=n, max_det=512, backbone=bb)
+    det.init_synthetic_weights(1234)
+    batches = [[helpers.make_image(4000 + 10 * b + i, 400 + 40 * ((b + i) % 3), 520 + 32 * (i % 2), n_blobs=5)
+                for i in range(n if b != 2 else n - 1)] for b in range(4)]
+    _, tn, _ = det.preprocess(batches[0])
+    h = det.forward(tn)
+    thr = float(np.quantile(np.concatenate([h[3 * l][:, 2:4].reshape(-1) for l in range(3)]), 0.99))
+    det.set_thresholds(thr, 0.45)
+    want = []
+    for frames in batches:
+        pre = [oracle.preprocess(f, 640, 640) for f in frames]
+        heads = det.forward(np.stack([p[1] for p in pre]))
+        want.append([oracle.decode_nms([x[b] for x in heads], 640, 640, np.float32(thr), 0.45, float(pre[b][2]))[:2]
+                     for b in range(len(frames))])
+    assert sum(len(d) for w in want for d, _ in w) > 20
+    got = []
+    det.submit(batches[0])
+    for b in range(1, len(batches)):
+        det.submit(batches[b])          # two in flight
+        got.append(det.collect())
+    got.append(det.collect())
+    for bi, (g, w) in enumerate(zip(got, want)):
+        assert len(g) == len(w)
+        for i, ((gd, gk), (od, ok)) in enumerate(zip(g, w)):
+            assert len(gd) == len(od), (bi, i)
+            assert np.array_equal(gd[:, 4], od[:, 4]), (bi, i)
+            np.testing.assert_allclose(gd[:, :4], od[:, :4], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(gk, ok, rtol=0, atol=1e-4)
     det.close()
 
 

@@ -97,3 +97,85 @@ def forward(P, x):
         outs += [cls, F.conv2d(o, T["head%d_bbox_weight" % st], T["head%d_bbox_bias" % st]),
                  F.conv2d(o, T["head%d_lmk_weight" % st], T["head%d_lmk_bias" % st])]
     return [t.numpy() for t in outs]
+
+
+class FoldedF32:
+    """The same network as `forward`, as an inference server would run it on a CPU: BatchNorm folded into the preceding
+    convolution (conv + bias + ReLU), plain f32, channels_last, torch.inference_mode.  Only the pre-activation BN1 of a
+    unit stays an explicit per-channel affine (it follows the residual add).  Used by bench.py's cpu_baseline leg as the
+    stand-in for the reference's Triton-CPU backend; `forward(P, x)` above stays the checker of the tests."""
+
+    def __init__(self, P):
+        self.w, self.b, self.aff = {}, {}, {}
+
+        def fold(name, with_bn=True):
+            w = torch.from_numpy(P[name + "_weight"]).float()
+            if with_bn:
+                s = torch.from_numpy(P[name + "_bn_gamma"] / np.sqrt(P[name + "_bn_var"] + EPS)).float()
+                self.b[name] = torch.from_numpy(P[name + "_bn_beta"]).float() - torch.from_numpy(P[name + "_bn_mean"]).float() * s
+                w = w * s.view(-1, 1, 1, 1)
+            else:
+                self.b[name] = torch.from_numpy(P[name + "_bias"]).float() if (name + "_bias") in P else None
+            self.w[name] = w.contiguous(memory_format=torch.channels_last)
+
+        def affine(name):
+            s = torch.from_numpy(P[name + "_gamma"] / np.sqrt(P[name + "_var"] + EPS)).float()
+            t = torch.from_numpy(P[name + "_beta"]).float() - torch.from_numpy(P[name + "_mean"]).float() * s
+            self.aff[name] = (s.view(1, -1, 1, 1), t.view(1, -1, 1, 1))
+
+        fold("conv0")
+        for s in (1, 2, 3, 4):
+            for u in range(1, UNITS[s] + 1):
+                p = "stage%d_unit%d" % (s, u)
+                affine(p + "_bn1")
+                fold(p + "_conv1"); fold(p + "_conv2"); fold(p + "_conv3", False)
+                if u == 1:
+                    fold(p + "_sc", False)
+        affine("bn1")
+        for nm in ("fpn_lat3", "fpn_lat2", "fpn_lat1", "fpn_aggr2", "fpn_aggr1"):
+            fold(nm)
+        for st in (32, 16, 8):
+            for nm in ("conv1", "ctx1", "ctx2", "ctx3a", "ctx3b"):
+                fold("ssh%d_%s" % (st, nm))
+            for nm in ("cls", "bbox", "lmk"):
+                fold("head%d_%s" % (st, nm), False)
+
+    def conv(self, y, k, stride=1, relu=True):
+        w = self.w[k]
+        y = F.conv2d(y, w, self.b[k], stride, w.shape[2] // 2)
+        return F.relu_(y) if relu else y
+
+    def act(self, y, k):
+        s, t = self.aff[k]
+        return F.relu_(y * s + t)
+
+    @torch.inference_mode()
+    def forward(self, x):
+        """x: [n,3,H,W] f32 -> the 9 head tensors (torch, cls soft-maxed)."""
+        y = F.max_pool2d(self.conv(x.contiguous(memory_format=torch.channels_last), "conv0", 2), 3, 2, 1)
+        taps = {}
+        for s in (1, 2, 3, 4):
+            for u in range(1, UNITS[s] + 1):
+                p = "stage%d_unit%d" % (s, u)
+                a = self.act(y, p + "_bn1")
+                if u == 1:
+                    taps[s] = a
+                stride = 2 if (u == 1 and s > 1) else 1
+                t = self.conv(self.conv(self.conv(a, p + "_conv1"), p + "_conv2", stride), p + "_conv3", relu=False)
+                y = t + (self.conv(a, p + "_sc", stride, relu=False) if u == 1 else y)
+        c1, c2, c3 = taps[3], taps[4], self.act(y, "bn1")
+        up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+        p3 = self.conv(c3, "fpn_lat3")
+        p2 = self.conv(self.conv(c2, "fpn_lat2") + up(p3), "fpn_aggr2")
+        p1 = self.conv(self.conv(c1, "fpn_lat1") + up(p2), "fpn_aggr1")
+        outs = []
+        for st, f in ((32, p3), (16, p2), (8, p1)):
+            k = "ssh%d_" % st
+            c = self.conv(f, k + "ctx1")
+            o = F.relu_(torch.cat([self.conv(f, k + "conv1", relu=False), self.conv(c, k + "ctx2", relu=False),
+                                   self.conv(self.conv(c, k + "ctx3a"), k + "ctx3b", relu=False)], 1))
+            cls = self.conv(o, "head%d_cls" % st, relu=False)
+            n, _, h, w = cls.shape
+            outs += [torch.softmax(cls.reshape(n, 2, 2, h, w), 1).reshape(n, 4, h, w),
+                     self.conv(o, "head%d_bbox" % st, relu=False), self.conv(o, "head%d_lmk" % st, relu=False)]
+        return outs
