@@ -64,7 +64,16 @@ def cpu_baseline(frames_np, thr):
     import unfolded_ref
     from oracle import oracle as O
     model = unfolded_ref.FoldedF32(unfolded_ref.make_params(1234))
-    cores = torch.get_num_threads()
+    # threads = the CPU share this process really has (cgroup quota / affinity), not the host's core count: torch would
+    # otherwise start one thread per host core and oversubscribe its share
+    cores = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
 
     def timed_pass(n):
         t0 = time.perf_counter()

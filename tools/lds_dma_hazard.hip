@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -142,6 +143,37 @@ template <int SHAPE> __global__ void __launch_bounds__(256) victim(int iters, un
     if (bad) atomicAdd(&bad_by_lane[lane], (unsigned long long)bad);
 }
 
+// ---- round 2: the minimal form.  Plain read-and-compare of a 4 KiB table, but the read executes under a PARTIAL EXEC
+//      mask: the lanes selected by `off_mask` (bit i = lane i) skip the read through a divergent branch, exactly what
+//      `if (tap outside the image) continue;` did to lane 0 of every fifth wave in the first-conv kernel.
+//      WIDTH 128 / 64: ds_read_b128 / 2 x ds_read_b64; ADDR 0 broadcast, 1 per-lane (lane*16), 2 MFMA-fragment pattern ----
+template <int WIDTH, int ADDR> __global__ void __launch_bounds__(256) victim_masked(int iters, unsigned long long off_mask, unsigned long long *bad_by_lane)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tab[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) tab[i] = pat(i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const bool skip = (off_mask >> lane) & 1ull;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int row = (it * 7 + (threadIdx.x >> 6)) & 31;
+        int off; // dwords
+        if (ADDR == 0) off = row * 32 + ((it & 7) * 4);
+        else if (ADDR == 1) off = ((row & 3) * 256 + lane * 4);
+        else off = ((lane & 15) * 16 + (lane >> 4) * 4 + (row & 3) * 256);
+        if (skip) continue; // divergent: the reads below run with EXEC = ~off_mask
+        uint32_t v[4];
+        if (WIDTH == 128) {
+            asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(*(__attribute__((ext_vector_type(4))) uint32_t *)v) : "v"(off * 4) : "memory");
+        } else {
+            asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(*(__attribute__((ext_vector_type(2))) uint32_t *)v), "=&v"(*(__attribute__((ext_vector_type(2))) uint32_t *)(v + 2)) : "v"(off * 4) : "memory");
+        }
+        for (int k = 0; k < 4; ++k) bad += v[k] != pat(off + k);
+    }
+    if (bad) atomicAdd(&bad_by_lane[lane], (unsigned long long)bad);
+}
+
 // SHAPE 8/9: eight LDS reads in flight (4 x b128 + 4 x b96, broadcast) with (9) or without (8) a global load pending,
 // the instruction pattern of the first-conv kernel that exposed the problem
 template <int WITH_VMEM> __global__ void __launch_bounds__(256) victim_multi(int iters, unsigned long long *bad_by_lane, const uint32_t *g)
@@ -223,30 +255,44 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
 {
     // VARIANT 0: as shipped then (1152 B of LDS, compiler-chosen ds_read_b128/b96); 1: LDS allocation padded to 8 KiB;
     // 2: table placed 4 KiB into the allocation
-    __shared__ __attribute__((aligned(16))) float ws_all[(VARIANT == 1 || VARIANT == 2) ? 2048 : 8 * 36];
+    // round-2 variants (all with explicit broadcast ds_read_b128 unless noted):
+    //  8: every wave sleeps ~25 us between the table fill + barrier and its first read ("errors sit early in a wave's
+    //     life, around the fill + barrier" would make this one clean);  9: 32 rounds like 7, but the FIRST round's result
+    //     is kept (early-life reads of a long-lived wave);  10: no divergent branch around the reads -- every lane
+    //     executes all nine taps with EXEC all ones, out-of-image taps are zeroed arithmetically;  11: one read in
+    //     flight at a time (each ds_read_b128 followed by its own lgkmcnt(0));  12: as 3 with the LDS allocation padded
+    //     to 8 KiB (allocation granule / neighbouring workgroup's LDS)
+    __shared__ __attribute__((aligned(16))) float ws_all[(VARIANT == 1 || VARIANT == 2 || VARIANT == 12) ? 2048 : 8 * 36];
     float *ws = ws_all + (VARIANT == 2 ? 1024 : 0);
-    if (VARIANT == 1) ws_all[2047 - (threadIdx.x & 255)] = 0.f;
+    if (VARIANT == 1 || VARIANT == 12) ws_all[2047 - (threadIdx.x & 255)] = 0.f;
     for (int i = threadIdx.x; i < 8 * 36; i += 256) ws[i] = bf16_bits_to_f32(w[i]);
     __syncthreads();
+    if (VARIANT == 8) {
+        for (int k = 0; k < 400; ++k) __builtin_amdgcn_s_sleep(127); // 400 x 127 x 64 clocks ~ 25 us at 2.1 GHz
+    }
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)B * Ho * Wo) return;
     const int wo = (int)(i % Wo);
     const int ho = (int)((i / Wo) % Ho);
     const int b = (int)(i / ((long long)Wo * Ho));
-    float acc[8];
-    for (int life = 0; life < (VARIANT == 7 ? 32 : 1); ++life) { // 7: long-lived waves, the result of the last round is kept
+    float acc[8], first[8];
+    for (int life = 0; life < ((VARIANT == 7 || VARIANT == 9) ? 32 : 1); ++life) { // 7 / 9: long-lived waves; 7 keeps the last round, 9 the first
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = bias[c];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int hi = 2 * ho - 1 + ky;
-        if ((unsigned)hi >= (unsigned)H) continue;
+        if (VARIANT != 10 && (unsigned)hi >= (unsigned)H) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int wi = 2 * wo - 1 + kx;
-            if ((unsigned)wi >= (unsigned)W) continue;
+            if (VARIANT != 10 && (unsigned)wi >= (unsigned)W) continue;
             uint2 p;
-            if (VARIANT == 6) { // no global load in the loop: a pixel made from the coordinates (bf16 2.0 .. 3.98)
+            if (VARIANT == 10) { // EXEC stays all ones: clamped address, pixel zeroed when the tap is outside the image
+                const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+                p = reinterpret_cast<const uint2 *>(x4)[((long long)b * H + (in ? hi : 0)) * W + (in ? wi : 0)];
+                if (!in) p = make_uint2(0, 0);
+            } else if (VARIANT == 6) { // no global load in the loop: a pixel made from the coordinates (bf16 2.0 .. 3.98)
                 p.x = (0x4000u + (uint32_t)((hi * 7 + wi * 3) & 0x7f)) | ((0x4000u + (uint32_t)((hi + wi) & 0x7f)) << 16);
                 p.y = 0x4000u + (uint32_t)((hi * 5 + wi) & 0x7f);
             } else {
@@ -274,7 +320,11 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
                     wv[0] = f4{l0.x, l0.y, h0.x, h0.y}; wv[1] = f4{l1.x, l1.y, h1.x, h1.y}; wv[2] = f4{l2.x, l2.y, h2.x, h2.y};
                     wv[3] = f4{l3.x, l3.y, h3.x, h3.y}; wv[4] = f4{l4.x, l4.y, h4.x, h4.y}; wv[5] = f4{l5.x, l5.y, h5.x, h5.y};
                     wv[6] = f4{l6.x, l6.y, h6.x, h6.y}; wv[7] = f4{l7.x, l7.y, h7.x, h7.y};
-                } else if (VARIANT == 3 || VARIANT == 6 || VARIANT == 7) {
+                } else if (VARIANT == 11) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=&v"(wv[c]) : "v"(a0 + (uint32_t)c * 144u) : "memory");
+                } else if (VARIANT == 3 || VARIANT == 6 || VARIANT == 7 || VARIANT == 8 || VARIANT == 9 || VARIANT == 10 || VARIANT == 12) {
                     asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
                                  "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
                                  "s_waitcnt lgkmcnt(0)"
@@ -311,7 +361,15 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
             }
         }
     }
-    if (VARIANT == 7) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+    if (VARIANT == 7 || VARIANT == 9) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+    if (VARIANT == 9 && life == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) first[c] = acc[c];
+    }
+    }
+    if (VARIANT == 9) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = first[c];
     }
     uint4 *dst = reinterpret_cast<uint4 *>(y + i * Cd);
     const uint2 lo = pack_bf16x4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
@@ -383,6 +441,11 @@ extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant,
         else if (variant == 4) f3_launch<4>(f.y);
         else if (variant == 5) f3_launch<5>(f.y);
         else if (variant == 6) f3_launch<6>(f.y);
+        else if (variant == 8) f3_launch<8>(f.y);
+        else if (variant == 9) f3_launch<9>(f.y);
+        else if (variant == 10) f3_launch<10>(f.y);
+        else if (variant == 11) f3_launch<11>(f.y);
+        else if (variant == 12) f3_launch<12>(f.y);
         else f3_launch<7>(f.y);
         hipLaunchKernelGGL(hz_compare, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, f.s, f.y, f.yref, npx, f.Cd, f.bad);
     }
@@ -497,7 +560,84 @@ static void run_multi(int dmode, const uint32_t *src, size_t nbytes, uint32_t *s
     }
 }
 
-int main()
+// round 2: only the first-conv victims, undisturbed and under the two MFMA disturbers, with the discriminating variants
+static int quick_main(const uint32_t *src, size_t nbytes, uint32_t *sink, hipStream_t sa)
+{
+    { // the minimal form first: masked lanes around a plain read-and-compare loop, MFMA-on-registers disturber
+        unsigned long long *d_bad;
+        hipStream_t sb;
+        CK(hipMalloc(&d_bad, 64 * sizeof(unsigned long long)));
+        CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        struct Case { const char *name; int width, addr; unsigned long long mask; };
+        const Case cases[] = {
+            {"broadcast b128, EXEC all ones", 128, 0, 0ull},
+            {"broadcast b128, lane 0 off", 128, 0, 1ull},
+            {"broadcast b128, lane 63 off", 128, 0, 1ull << 63},
+            {"broadcast b128, lane 20 off", 128, 0, 1ull << 20},
+            {"broadcast b128, lanes 0-31 off", 128, 0, 0xffffffffull},
+            {"broadcast b128, lanes 48-63 off", 128, 0, 0xffffull << 48},
+            {"per-lane b128 (lane*16), lane 0 off", 128, 1, 1ull},
+            {"fragment b128 ((l&15)*64+(l>>4)*16), lane 0 off", 128, 2, 1ull},
+            {"fragment b128, lanes 0-15 off", 128, 2, 0xffffull},
+            {"broadcast 2 x b64, lane 0 off", 64, 0, 1ull},
+            {"fragment 2 x b64, lane 0 off", 64, 2, 1ull},
+        };
+        for (int d = 0; d < 2; ++d) {
+            printf("minimal form, disturber: %s\n", d ? "32 MFMA per step on register operands only (no LDS traffic)" : "none");
+            for (const Case &c : cases) {
+                CK(hipMemset(d_bad, 0, 64 * sizeof(unsigned long long)));
+                CK(hipDeviceSynchronize());
+                if (d) hipLaunchKernelGGL(disturber<6>, dim3(4096), dim3(256), 32768, sa, src, nbytes, 200, sink);
+                for (int rep = 0; rep < 4; ++rep) {
+                    if (c.width == 128 && c.addr == 0) hipLaunchKernelGGL((victim_masked<128, 0>), dim3(4096), dim3(256), 0, sb, 2000, c.mask, d_bad);
+                    else if (c.width == 128 && c.addr == 1) hipLaunchKernelGGL((victim_masked<128, 1>), dim3(4096), dim3(256), 0, sb, 2000, c.mask, d_bad);
+                    else if (c.width == 128) hipLaunchKernelGGL((victim_masked<128, 2>), dim3(4096), dim3(256), 0, sb, 2000, c.mask, d_bad);
+                    else if (c.addr == 0) hipLaunchKernelGGL((victim_masked<64, 0>), dim3(4096), dim3(256), 0, sb, 2000, c.mask, d_bad);
+                    else hipLaunchKernelGGL((victim_masked<64, 2>), dim3(4096), dim3(256), 0, sb, 2000, c.mask, d_bad);
+                }
+                CK(hipDeviceSynchronize());
+                unsigned long long h[64], tot = 0, q[4] = {0, 0, 0, 0};
+                CK(hipMemcpy(h, d_bad, sizeof h, hipMemcpyDeviceToHost));
+                for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
+                printf("  %-52s bad reads %10llu  by lane quarter [%llu %llu %llu %llu]\n", c.name, tot, q[0], q[1], q[2], q[3]);
+                fflush(stdout);
+            }
+        }
+    }
+    hazard_f3_init();
+    const char *fn[10] = {"explicit broadcast b128 (as round 1)", "explicit 2 x b64", "long-lived (32 rounds), LAST round kept",
+                          "long-lived (32 rounds), FIRST round kept", "25 us sleep between fill+barrier and the first read",
+                          "EXEC all ones (no branch around the reads)", "one b128 in flight at a time", "LDS allocation padded to 8 KiB",
+                          "compiler-chosen reads", "b128, counted waits (reads still in flight)"};
+    const int fv[10] = {3, 4, 7, 9, 8, 10, 11, 12, 0, 5};
+    const int dmodes[3] = {3, 7, 5};
+    const char *dn[3] = {"none", "32 MFMA per step on register operands only (no LDS traffic)", "LDS-DMA dwordx4 + fragment reads + 32 MFMA per step"};
+    for (int d = 0; d < 3; ++d) {
+        printf("disturber: %s\n", dn[d]);
+        for (int k = 0; k < 10; ++k) {
+            CK(hipDeviceSynchronize());
+            hazard_f3_reference(fv[k]);
+            if (dmodes[d] == 7) hipLaunchKernelGGL(disturber<6>, dim3(8192), dim3(256), 32768, sa, src, nbytes, fv[k] == 8 ? 1600 : 400, sink);
+            else if (dmodes[d] == 5) hipLaunchKernelGGL(disturber<4>, dim3(8192), dim3(256), 32768, sa, src, nbytes, fv[k] == 8 ? 1600 : 400, sink);
+            unsigned long long h[64];
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0, g_f3.s));
+            hazard_f3_run(fv[k], 12, h);
+            CK(hipEventRecord(e1, g_f3.s));
+            CK(hipDeviceSynchronize());
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long tot = 0, q[4] = {0, 0, 0, 0};
+            for (int l = 0; l < 64; ++l) { tot += h[l]; q[l >> 4] += h[l]; }
+            printf("  %-52s bad elements %8llu  by lane quarter [%llu %llu %llu %llu]  (12 launches, %.1f ms)\n", fn[k], tot, q[0], q[1], q[2], q[3], ms);
+            fflush(stdout);
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
 {
     const size_t nbytes = 256u << 20;
     uint32_t *src, *sink;
@@ -509,6 +649,7 @@ int main()
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    if (argc > 1 && !strcmp(argv[1], "quick")) return quick_main(src, nbytes, sink, sa);
     const char *dn[8] = {"LDS-DMA dwordx4 (buffer_load_dwordx4 lds)", "LDS-DMA dword (buffer_load_dword lds)", "global_load + ds_write_b128", "none",
                          "LDS-DMA dwordx4 + 16 fragment ds_read_b128 per step", "LDS-DMA dwordx4 + fragment reads + 32 MFMA per step",
                          "fragment ds_read_b128 + 32 MFMA per step, no DMA", "32 MFMA per step on register operands only (no LDS traffic)"};

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Runs single network ops repeatedly (for rocprofv3 --pmc / --kernel-trace on one layer shape).
-usage: python tools/op_bench.py --ops 27,54 --reps 20 [--batch 32] [--tile 0|1|2]"""
+"""Times single network ops (HIP events around the launch, median of --reps runs) under forced conv tile configurations
+(rfd_debug_set_conv_tile) and batch sizes, interleaved in ONE process (A/B rule: never compare across processes).
+usage: python tools/op_bench.py --ops 13,25 --tiles 0,7 --batches 32,16 [--reps 20] [--rounds 3]"""
 import argparse
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rs-face-detection_amd", "python"), os.path.join(ROOT, "tests")):
@@ -15,13 +15,15 @@ import rfd_hip  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--ops", default="27")
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--tile", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--batches", default="32")
+ap.add_argument("--tiles", default="0")
 a = ap.parse_args()
-det = rfd_hip.RetinaFaceDetection(max_batch_size=a.batch, max_det=16)
+batches = [int(x) for x in a.batches.split(",")]
+tiles = [int(x) for x in a.tiles.split(",")]
+det = rfd_hip.RetinaFaceDetection(max_batch_size=max(batches), max_det=16)
 det.init_synthetic_weights(1234)
 g = rfd_hip.Graph()
-det.debug_set_conv_tile(a.tile)
 rng = np.random.default_rng(0)
 for t in range(g.num_tensors):  # random bf16 activations everywhere (never bench on zeros)
     td = g.tensors[t]
@@ -29,16 +31,33 @@ for t in range(g.num_tensors):  # random bf16 activations everywhere (never benc
         continue
     x = np.maximum(rng.normal(0, 1, size=(1, td.height, td.width, td.channels)).astype(np.float32), 0)
     bits = (x.view(np.uint32) >> 16).astype(np.uint16)
-    det.debug_write(t, np.repeat(bits, a.batch, axis=0))
-for op in [int(x) for x in a.ops.split(",")]:
-    o = g.ops[op]
-    L = g.layers[o.layer]
-    det.set_profiling(True)
-    det.debug_run(a.batch, op, op)
-    ts = []
-    for _ in range(a.reps):
-        det.debug_run(a.batch, op, op)
-        ts.append(float(det.op_profile(g.num_ops)[op]) * 1e-3)
-    dt = float(np.median(ts))
-    fl = 2.0 * o.macs * a.batch
-    print("op %d %s: %.1f us/launch (HIP events, median) %.1f TF" % (op, L.name.decode(), dt * 1e6, fl / dt / 1e12))
+    det.debug_write(t, np.repeat(bits, max(batches), axis=0))
+det.set_profiling(True)
+for _ in range(20):  # clocks up
+    det.debug_run(max(batches), 0, -1)
+ops = [int(x) for x in a.ops.split(",")] if a.ops != "all" else [k for k, o in enumerate(g.ops) if o.kind in (2, 6)]
+res = {}
+for rnd in range(a.rounds):
+    for B in batches:
+        for tile in tiles:
+            det.debug_set_conv_tile(tile)
+            for op in ops:
+                det.debug_run(B, op, op)
+                ts = []
+                for _ in range(a.reps):
+                    det.debug_run(B, op, op)
+                    ts.append(float(det.op_profile(g.num_ops)[op]) * 1e3)
+                res.setdefault((B, tile, op), []).append(float(np.median(ts)))
+for B in batches:
+    print("batch %d: us per launch (median over %d rounds of medians of %d), tiles %s" % (B, a.rounds, a.reps, tiles))
+    tot = {t: 0.0 for t in tiles}
+    for op in ops:
+        o = g.ops[op]
+        L = g.layers[o.layer]
+        row = [float(np.median(res[(B, t, op)])) for t in tiles]
+        for t, v in zip(tiles, row):
+            tot[t] += v
+        fl = 2.0 * o.macs * B
+        print("%3d %-22s k%d %4d->%4d  " % (op, L.name.decode(), L.kh, L.cin, L.cout) +
+              "  ".join("%7.1f us %6.0f TF" % (v, fl / v / 1e6) for v in row))
+    print("    totals", {t: round(v, 1) for t, v in tot.items()})
