@@ -648,6 +648,158 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
     conv_epilogue<TM, TN, WM, WN>(p, acc, resv, m0, n0, wm, wn, frow, fq, M);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels (conv2 of the stage-1 units at 160 x 160, the SSH context convs): the whole
+// filter bank is 72 KiB, so a PERSISTENT workgroup keeps it in LDS for its lifetime and walks 16 x 16-pixel output tiles;
+// per tile only the 18 x 18-pixel halo tile (41 KiB) is staged -- ONCE for all nine taps -- into a double buffer while the
+// previous tile computes.  Through the CU's load path that is 41 KiB in + 32 KiB out per 18.9 MFLOP (257 FLOP/B) where
+// the generic 128 x 64 tile moves 221 KiB + 16 KiB per 9.4 MFLOP (40 FLOP/B); the generic kernel ran these layers at
+// 13-14 TB/s of L2->LDS traffic, i.e. load-path bound (0.52-0.56 PF/s).
+// 8 waves = 4 (pixel rows) x 2 (channels); a wave owns 4 spatial rows x 16 columns x 32 channels; all 18 (tap, kk) steps are
+// unrolled with immediate LDS offsets.  The halo image is stored pixel-major (row R = hy * 18 + hx, 128 B per pixel) with the
+// chunk swizzle keyed on hx & 7, so the XOR of a tap depends on kx only.  LDS: 72 KiB + 2 x 41 KiB = 154 KiB, 1 workgroup / CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int kC64T = 16, kC64H = kC64T + 2, kC64HP = 41 /* pieces of 8 rows */;
+__global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, int tiles_x, int tiles_y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Wt = reinterpret_cast<bf16_t *>(smem);       // [9][64][64]
+    bf16_t *Xh = Wt + 9 * 64 * 64;                        // [2][kC64HP*8][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int lr = lane >> 3, slot = lane & 7, frow = lane & 15, fq = lane >> 4;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * p.H * p.W * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (uint32_t)(64 * 576 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (uint32_t)((size_t)p.B * p.H * p.W * p.ldy * 2), 0x00020000);
+    if ((int)blockIdx.x >= ntiles) return;
+
+    // ---- filter bank -> LDS, once: 72 pieces (tap t, rows 8 q .. 8 q + 7), wave w takes pieces w, w + 8, ...
+    //      LDS row rho of a tap holds output channel perm(rho) (8 consecutive channels per lane in the epilogue) ----
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int piece = wave + 8 * i, t = piece >> 3, rho = (piece & 7) * 8 + lr;
+        const int rw_ = rho & 31, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = (rho - rw_) + fq_ * 8 + (i_ & 1) * 4 + r_;
+        blds16(rw, (uint32_t)(((size_t)chn * 576 + t * 64 + ((slot ^ lr) << 3)) * 2), 0, Wt + piece * 512);
+    }
+    // ---- halo staging: piece q of this wave covers image rows R = (wave + 8 q) * 8 + lr of the halo tile ----
+    constexpr int HQ = (kC64HP + 7) / 8; // 6 pieces per wave at most
+    int hy[HQ], hx[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int R = (wave + 8 * q) * 8 + lr;
+        hy[q] = R / kC64H;
+        hx[q] = R - hy[q] * kC64H;
+    }
+    auto stage_halo = [&](int tile, int buf) {
+        const int b = tile / (tiles_x * tiles_y), rem = tile - b * tiles_x * tiles_y;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int piece = wave + 8 * q;
+            if (piece < kC64HP) {
+                const int gy = ty * kC64T - 1 + hy[q], gx = tx * kC64T - 1 + hx[q];
+                const bool ok = hy[q] < kC64H && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const uint32_t off = (uint32_t)(((((size_t)b * p.H + gy) * p.W + gx) * p.ldx + p.x_coff + ((slot ^ (hx[q] & 7)) << 3)) * 2);
+                blds16(rx, ok ? off : kOob, 0, Xh + buf * (kC64HP * 512) + piece * 512);
+            }
+        }
+    };
+    // per-lane read bases: B fragment (j) = pixel (4 wm + j, frow) of the tile -> halo row (4 wm + j + ky) * 18 + frow + kx
+    const bf16_t *xbase = Xh + ((wm * 4) * kC64H + frow) * 64;
+    const bf16_t *wbase = Wt + (wn * 32 + frow) * 64;
+    int xsw[3][2]; // chunk index of (kx, kk) for this lane: (kk * 4 + fq) ^ ((frow + kx) & 7)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xsw[kx][kk] = ((kk * 4 + fq) ^ ((frow + kx) & 7)) << 3;
+    const int wsw0 = ((0 * 4 + fq) ^ (frow & 7)) << 3, wsw1 = ((1 * 4 + fq) ^ (frow & 7)) << 3;
+    float bias[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + wn * 32 + fq * 8), b1 = *reinterpret_cast<const float4 *>(p.bias + wn * 32 + fq * 8 + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+
+    int buf = 0;
+    stage_halo(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        // this tile's halo (and, the first time, the filter bank) has landed in every wave; the other buffer is free.
+        // After the first tile the 4 output stores of the previous tile are the only younger operations of this wave
+        // (buffer stores, always issued: out-of-image pixels get an out-of-range offset), and they may stay in flight.
+        if (tile == (int)blockIdx.x) wait_vmcnt<0>();
+        else wait_vmcnt<4>();
+        asm volatile("s_barrier" ::: "memory");
+        if (next < ntiles) stage_halo(next, buf ^ 1);
+        const bf16_t *xb = xbase + buf * (kC64HP * 512);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 af[2], bfr[4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8 *>(wbase + ((ky * 3 + kx) * 64 + i * 16) * 64 + (kk ? wsw1 : wsw0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bfr[j] = *reinterpret_cast<const bf16x8 *>(xb + ((j + ky) * kC64H + kx) * 64 + xsw[kx][kk]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+        // epilogue: + bias, ReLU, 16-byte stores (8 consecutive channels of one pixel per lane)
+        const int b = tile / (tiles_x * tiles_y), rem = tile - b * tiles_x * tiles_y;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int ox = tx * kC64T + frow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = ty * kC64T + wm * 4 + j;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = acc[0][j][k] + bias[k];
+                o[4 + k] = acc[1][j][k] + bias[4 + k];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+            }
+            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const uint32_t yoff = (uint32_t)(((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + p.y_coff + wn * 32 + fq * 8) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, (oy < p.H && ox < p.W) ? yoff : kOob, 0, 0);
+        }
+        buf ^= 1;
+    }
+}
+
+static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
+{
+    const int tiles_x = ceil_div(p.W, kC64T), tiles_y = ceil_div(p.H, kC64T);
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ncu = 256;
+    const int per = ceil_div(ntiles, ncu);
+    const int grid = ceil_div(ntiles, per); // even share per persistent workgroup: no tail
+    const size_t lds = (size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t);
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv3x3_c64_kernel), (int)lds));
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
 template <int BN, int WAVES_M, int WAVES_N>
 static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
 {
@@ -898,6 +1050,11 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                        p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout && (!p.y || p.ldy == p.Cout) &&
                        (p.Cin == 128 || p.Cin == 256) && (p.force_tile == 0 || p.force_tile == 6);
     if (pw_ok) return p.Cin == 128 ? launch_pw_stream<2>(p, s) : launch_pw_stream<4>(p, s);
+    // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
+    const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
+                        !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
+                        (p.force_tile == 0 || p.force_tile == 6);
+    if (c64_ok) return launch_conv3x3_c64(p, s);
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
     if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);

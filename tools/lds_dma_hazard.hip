@@ -324,6 +324,19 @@ __global__ void __launch_bounds__(256) victim_f3(const uint16_t *__restrict__ x4
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
                         asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=&v"(wv[c]) : "v"(a0 + (uint32_t)c * 144u) : "memory");
+                } else if (VARIANT == 13) { // as 3, with ~64 idle cycles between the branch's EXEC write and the first read
+                    asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                                 "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
+                                 "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7])
+                                 : "v"(a0) : "memory");
+                } else if (VARIANT == 14) { // as 3, with ~64 idle cycles between the last read's return and the EXEC restore
+                    asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
+                                 "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
+                                 "s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15"
+                                 : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7])
+                                 : "v"(a0) : "memory");
                 } else if (VARIANT == 3 || VARIANT == 6 || VARIANT == 7 || VARIANT == 8 || VARIANT == 9 || VARIANT == 10 || VARIANT == 12) {
                     asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:144\n ds_read_b128 %2, %8 offset:288\n ds_read_b128 %3, %8 offset:432\n"
                                  "ds_read_b128 %4, %8 offset:576\n ds_read_b128 %5, %8 offset:720\n ds_read_b128 %6, %8 offset:864\n ds_read_b128 %7, %8 offset:1008\n"
@@ -446,6 +459,8 @@ extern "C" __attribute__((visibility("default"))) int hazard_f3_run(int variant,
         else if (variant == 10) f3_launch<10>(f.y);
         else if (variant == 11) f3_launch<11>(f.y);
         else if (variant == 12) f3_launch<12>(f.y);
+        else if (variant == 13) f3_launch<13>(f.y);
+        else if (variant == 14) f3_launch<14>(f.y);
         else f3_launch<7>(f.y);
         hipLaunchKernelGGL(hz_compare, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, f.s, f.y, f.yref, npx, f.Cd, f.bad);
     }
@@ -561,9 +576,10 @@ static void run_multi(int dmode, const uint32_t *src, size_t nbytes, uint32_t *s
 }
 
 // round 2: only the first-conv victims, undisturbed and under the two MFMA disturbers, with the discriminating variants
+static int argc_quick2 = 0; // "quick2": skip the variants already settled
 static int quick_main(const uint32_t *src, size_t nbytes, uint32_t *sink, hipStream_t sa)
 {
-    { // the minimal form first: masked lanes around a plain read-and-compare loop, MFMA-on-registers disturber
+    if (!argc_quick2) { // the minimal form first: masked lanes around a plain read-and-compare loop, MFMA-on-registers disturber
         unsigned long long *d_bad;
         hipStream_t sb;
         CK(hipMalloc(&d_bad, 64 * sizeof(unsigned long long)));
@@ -605,16 +621,18 @@ static int quick_main(const uint32_t *src, size_t nbytes, uint32_t *sink, hipStr
         }
     }
     hazard_f3_init();
-    const char *fn[10] = {"explicit broadcast b128 (as round 1)", "explicit 2 x b64", "long-lived (32 rounds), LAST round kept",
+    const char *fn[12] = {"explicit broadcast b128 (as round 1)", "explicit 2 x b64", "long-lived (32 rounds), LAST round kept",
                           "long-lived (32 rounds), FIRST round kept", "25 us sleep between fill+barrier and the first read",
                           "EXEC all ones (no branch around the reads)", "one b128 in flight at a time", "LDS allocation padded to 8 KiB",
-                          "compiler-chosen reads", "b128, counted waits (reads still in flight)"};
-    const int fv[10] = {3, 4, 7, 9, 8, 10, 11, 12, 0, 5};
+                          "compiler-chosen reads", "b128, counted waits (reads still in flight)",
+                          "64 idle cycles between the EXEC write and the reads", "64 idle cycles after the reads landed"};
+    const int fv[12] = {3, 4, 7, 9, 8, 10, 11, 12, 0, 5, 13, 14};
     const int dmodes[3] = {3, 7, 5};
     const char *dn[3] = {"none", "32 MFMA per step on register operands only (no LDS traffic)", "LDS-DMA dwordx4 + fragment reads + 32 MFMA per step"};
     for (int d = 0; d < 3; ++d) {
         printf("disturber: %s\n", dn[d]);
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 12; ++k) {
+            if (argc_quick2 && k != 0 && k != 5 && k < 10) continue;
             CK(hipDeviceSynchronize());
             hazard_f3_reference(fv[k]);
             if (dmodes[d] == 7) hipLaunchKernelGGL(disturber<6>, dim3(8192), dim3(256), 32768, sa, src, nbytes, fv[k] == 8 ? 1600 : 400, sink);
@@ -649,7 +667,8 @@ int main(int argc, char **argv)
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    if (argc > 1 && !strcmp(argv[1], "quick")) return quick_main(src, nbytes, sink, sa);
+    if (argc > 1 && !strcmp(argv[1], "quick2")) argc_quick2 = 1;
+    if (argc > 1 && !strncmp(argv[1], "quick", 5)) return quick_main(src, nbytes, sink, sa);
     const char *dn[8] = {"LDS-DMA dwordx4 (buffer_load_dwordx4 lds)", "LDS-DMA dword (buffer_load_dword lds)", "global_load + ds_write_b128", "none",
                          "LDS-DMA dwordx4 + 16 fragment ds_read_b128 per step", "LDS-DMA dwordx4 + fragment reads + 32 MFMA per step",
                          "fragment ds_read_b128 + 32 MFMA per step, no DMA", "32 MFMA per step on register operands only (no LDS traffic)"};
