@@ -359,36 +359,67 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 // drain) and the workgroup relaunch: 3.1 TB/s of HBM-side traffic where the tensors need 5+.
 // Here a workgroup is PERSISTENT and X-STATIONARY: it owns a stripe of 128-pixel tiles; per tile the whole activation tile
 // [128][K] is staged once (instead of once per N tile: -25 % bytes through the CU's load path), then the weight K-steps of
-// all N / 128 output chunks stream through a 3-slot ring without a break -- across chunk and tile boundaries -- so the
-// next operands are always in flight while a chunk's epilogue stores drain.  8 waves: 4 (pixels) x 2 (channels), 32 x 64
-// outputs each.  LDS: K = 256: 64 KiB + 48 KiB.
+// all N / 128 output chunks stream through a 3-slot ring without a break -- across chunk and tile boundaries.  The
+// residual of chunk c+1 is requested (straight into registers, two alternating sets) BEFORE the stores of chunk c are
+// issued, bias / scale / shift sit in an LDS table, and every wait is a COUNTED s_waitcnt: the stores of chunk c drain while
+// chunk c+1's MFMAs run and chunk c+2's residual is already on its way -- the memory pipeline never sees a gap except at a
+// tile's first step.  The residual loads are inline asm (hipcc would wait vmcnt(0) at their use and drain the DMAs);
+// every output goes through a buffer store that is ALWAYS issued (out-of-range offset for rows >= M), so that the
+// operation counts the waits rely on are exact.  8 waves: 4 (pixels) x 2 (channels), 32 x 64 outputs each.
+// Per wave and chunk, in issue order:  W W (step 0) ... W W (step NK-1) | R R R R (next chunk) | S x ST.
 // ------------------------------------------------------------------------------------------------
-template <int NK>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 make_srd(const void *base, uint32_t bytes)
+{
+    const uint64_t a = (uint64_t)base;
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+// one 16-byte buffer load the compiler does not count (the destination is valid only after the caller's own wait)
+__device__ __forceinline__ void asm_buffer_load_b128(u32x4 &dst, uint32_t voff, const u32x4 &srd)
+{
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(srd) : "memory");
+}
+
+template <int NK, bool HAS_Y, bool HAS_Y2>
 __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 {
     constexpr int BM = 128, WSLOTS = 3, PF = 2;     // PF = weight K-steps in flight beyond the one being consumed
-    constexpr int WM = 32, WN = 64, TM = 2, TN = 4, TH = 2;
+    constexpr int ST = (HAS_Y ? 4 : 0) + (HAS_Y2 ? 4 : 0);
+    constexpr int N_STEP = 2 * (PF - 1);              // steady state: only the next weight step may stay in flight
+    constexpr int N_STEP_HEAD = 2 * (PF - 1) + 4 + ST; // first PF steps of a chunk: + the previous epilogue's loads and stores
+    constexpr int N_RES = ST + 2 * NK + 4;            // younger than this chunk's residual: stores, NK weight steps, next residual
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);   // [NK][BM*64]
     bf16_t *Ws = Xs + NK * BM * 64;                  // [WSLOTS][128*64]
+    float *Tab = reinterpret_cast<float *>(Ws + WSLOTS * 128 * 64); // bias [N] | scale2 [N] | shift2 [N]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    const int M = p.B * p.Ho * p.Wo, K = p.Cin;
-    const int NC = p.Cout >> 7;                      // output chunks of 128 channels
+    const int M = p.B * p.Ho * p.Wo, K = p.Cin, N = p.Cout;
+    const int NC = N >> 7;                           // output chunks of 128 channels (even)
     const int tiles_m = (M + BM - 1) / BM;
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+    if ((int)blockIdx.x >= tiles_m) return;
+
+    for (int c = tid; c < N; c += 512) {
+        Tab[c] = p.bias[c];
+        if (HAS_Y2) { Tab[N + c] = p.scale2[c]; Tab[2 * N + c] = p.shift2[c]; }
+    }
+    __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)N * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(HAS_Y ? p.y : p.y2, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc(p.y2 ? p.y2 : p.y, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
+    const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
     // weight pieces of a K-step (16 x [8 rows x 128 B]): wave w stages pieces w and w + 8; LDS row rho holds output channel
     // perm(rho) of the chunk, so that a lane's accumulators are 8 consecutive channels (see conv_igemm_kernel)
     uint32_t woff[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int rho = (wave + 8 * q) * 8 + lr;
-        const int rw_ = rho % WN, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int rw_ = rho & 63, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
         const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
         woff[q] = (uint32_t)(((size_t)chn * K + chunk * 8) * 2);
     }
@@ -401,7 +432,21 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
         if (++wi_kt == NK) { wi_kt = 0; if (++wi_nc == NC) wi_nc = 0; }
         wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
     };
-    if ((int)blockIdx.x >= tiles_m) return;
+    // this lane's output position inside a (tile, chunk): pixel rows wm*32 + j*16 + frow, channels wn*64 + h*32 + fq*8 .. +7
+    const uint32_t lane_off = (uint32_t)((((size_t)(wm * 32 + frow)) * N + wn * 64 + fq * 8) * 2);
+    auto issue_res = [&](u32x4 (&r)[4], int mt, int nc) { // 4 loads, always issued (out of range -> zeros)
+        const bool tile_ok = mt < tiles_m;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = tile_ok && mt * BM + wm * 32 + j * 16 + frow < M;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                asm_buffer_load_b128(r[j * 2 + h], ok ? lane_off + (uint32_t)((((size_t)mt * BM + j * 16) * N + (nc << 7) + h * 32) * 2) : kOob, rres);
+        }
+    };
+
+    u32x4 resA[4], resB[4];
+    issue_res(resA, blockIdx.x, 0);
 #pragma unroll
     for (int i = 0; i < PF; ++i) issue_w();
     int cslot = 0; // ring slot of the weight step consumed next
@@ -419,60 +464,108 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
                 blds16(rx, m < M ? (uint32_t)(((size_t)m * K + chunk * 8) * 2) : kOob, (uint32_t)(kt << 7),
                        Xs + kt * BM * 64 + (wave + 8 * q) * 512);
             }
-        for (int nc = 0; nc < NC; ++nc) {
-            const int n0 = nc << 7;
-            uint4 resv[TM][TH];
-            conv_prefetch_residual<TM, TH, WM, WN>(p, resv, m0, n0, wm, wn, frow, fq, M, 1);
-            f32x4 acc[TN][TM];
+        auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4]) __attribute__((always_inline)) {
+            f32x4 acc[4][2];
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) {
-                // needs W(step) -- and in the first chunk X(kt), which was issued AFTER the weight steps in flight at the
-                // tile boundary, so everything but the younger activation steps must have landed there
-                if (nc == 0) {
-                    switch (NK - 1 - kt) { // X(kt+1 ..) = 2 DMAs each, plus the 2 * kt weight DMAs issued since the tile began
-                    case 0: wait_vmcnt<0>(); break; // (conservative: drains)
-                    default: wait_vmcnt<2>(); break; // at least the youngest activation / weight step may stay in flight
-                    }
-                } else {
-                    wait_vmcnt<2 * (PF - 1)>();
-                }
+                // first chunk of a tile: X(kt) is younger than every weight step in flight; 2 (NK - 1) operations are
+                // younger than X(kt) at step kt (the later activation steps + the weight steps issued since).  Otherwise:
+                // W(step) was issued PF steps ago.
+                if (nc == 0) wait_vmcnt<2 * (NK - 1)>();
+                else if (kt < PF) wait_vmcnt<N_STEP_HEAD>();
+                else wait_vmcnt<N_STEP>();
                 asm volatile("s_barrier" ::: "memory");
                 issue_w();
-                const bf16_t *xs = Xs + kt * BM * 64 + (wm * WM) * 64;
-                const bf16_t *ws = Ws + cslot * 128 * 64 + (wn * WN) * 64;
+                const bf16_t *xs = Xs + kt * BM * 64 + (wm * 32) * 64;
+                const bf16_t *ws = Ws + cslot * 128 * 64 + (wn * 64) * 64;
                 cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 af[TN], bfr[TM];
+                    bf16x8 af[4], bfr[2];
                     const int ch = kk * 4 + fq;
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) {
+                    for (int i = 0; i < 4; ++i) {
                         const int r = i * 16 + frow;
                         af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3));
                     }
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) {
+                    for (int j = 0; j < 2; ++j) {
                         const int r = j * 16 + frow;
                         bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3));
                     }
 #pragma unroll
-                    for (int i = 0; i < TN; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < TM; ++j)
+                        for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
             }
-            conv_epilogue<TM, TN, WM, WN>(p, acc, resv, m0, n0, wm, wn, frow, fq, M);
+            // ---- epilogue: the NEXT chunk's residual first (next tile's chunk 0 after the last chunk), then this one's ----
+            if (nc + 1 < NC) issue_res(nxt, mt, nc + 1);
+            else issue_res(nxt, mt + (int)gridDim.x, 0);
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(N_RES));
+            __builtin_amdgcn_sched_barrier(0);
+            const int n0 = nc << 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n0 + wn * 64 + h * 32 + fq * 8;
+                float bias[8], s2[8], t2[8];
+                {
+                    const float4 b0 = *reinterpret_cast<const float4 *>(Tab + n), b1 = *reinterpret_cast<const float4 *>(Tab + n + 4);
+                    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+                }
+                if (HAS_Y2) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(Tab + N + n), a1 = *reinterpret_cast<const float4 *>(Tab + N + n + 4);
+                    const float4 c0 = *reinterpret_cast<const float4 *>(Tab + 2 * N + n), c1 = *reinterpret_cast<const float4 *>(Tab + 2 * N + n + 4);
+                    s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
+                    t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = m0 + wm * 32 + j * 16 + frow;
+                    const uint32_t off = m < M ? (uint32_t)(((size_t)m * N + n) * 2) : kOob;
+                    const u32x4 rv = cur[j * 2 + h];
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[2 * h][j][k] + bias[k];
+                        v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
+                        v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
+                    }
+                    if (HAS_Y) {
+                        float o[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = p.relu ? fmaxf(v[k], 0.f) : v[k];
+                        const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, off, 0, 0);
+                    }
+                    if (HAS_Y2) {
+                        float o[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * s2[k] + t2[k], 0.f);
+                        const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry2, off, 0, 0);
+                    }
+                }
+            }
+        };
+        for (int nc = 0; nc < NC; nc += 2) { // two chunks per turn: the residual register sets alternate without copies
+            do_chunk(nc, resA, resB);
+            do_chunk(nc + 1, resB, resA);
         }
     }
-    wait_vmcnt<0>(); // the weight steps issued beyond the last consumed one
+    wait_vmcnt<0>(); // weight steps and residual loads issued beyond the end
 }
 
-template <int NK> static int launch_pw_stream(const ConvParams &p, hipStream_t s)
+template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
@@ -486,12 +579,18 @@ template <int NK> static int launch_pw_stream(const ConvParams &p, hipStream_t s
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    const size_t lds = (size_t)(NK * 128 + 3 * 128) * 64 * sizeof(bf16_t);
+    const size_t lds = (size_t)(NK * 128 + 3 * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
     static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_stream_kernel<NK>), (int)lds));
-    hipLaunchKernelGGL(pw_stream_kernel<NK>, dim3(grid), dim3(512), lds, s, p);
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_stream_kernel<NK, HAS_Y, HAS_Y2>), 160 * 1024));
+    hipLaunchKernelGGL((pw_stream_kernel<NK, HAS_Y, HAS_Y2>), dim3(grid), dim3(512), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
+}
+template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
+{
+    if (p.y && p.y2) return launch_pw_stream<NK, true, true>(p, s);
+    if (p.y) return launch_pw_stream<NK, true, false>(p, s);
+    return launch_pw_stream<NK, false, true>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1049,7 +1148,7 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                        !p.res_up2 && !p.res_post && p.ldx == p.Cin && p.x_coff == 0 && p.Cout % 128 == 0 && p.Cout >= 4 * p.Cin &&
                        p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout && (!p.y || p.ldy == p.Cout) &&
                        (p.Cin == 128 || p.Cin == 256) && (p.force_tile == 0 || p.force_tile == 6);
-    if (pw_ok) return p.Cin == 128 ? launch_pw_stream<2>(p, s) : launch_pw_stream<4>(p, s);
+    if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024) return p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&

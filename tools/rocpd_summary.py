@@ -14,7 +14,8 @@ import sqlite3
 import statistics
 import sys
 
-NET = ("conv_igemm_kernel", "conv3x3_kx_kernel", "conv_b2b_s1_kernel", "stem_kernel")
+NET = ("conv_igemm_kernel", "conv3x3_kx_kernel", "conv_b2b_s1_kernel", "stem_kernel", "pw_stream_kernel", "conv3x3_c64_kernel",
+       "conv_tile256_kernel")
 
 
 def is_net(name):
@@ -128,8 +129,44 @@ def mfma(db_path, out_json):
                       "per_kernel": {k: round(v["mfma_util"], 4) for k, v in rows.items() if v["mfma_util"] is not None}}))
 
 
+def timeline(path, out_txt):
+    """One pass of the timed configuration as a text timeline: every kernel with its queue, start and end relative to the
+    pass's preprocess launch, plus how much of the pass had 0 / 1 / 2+ network kernels in flight."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    q = "select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")
+    rows = db.execute(q).fetchall()
+    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]]
+    with open(out_txt, "w") as f:
+        f.write("columns of `kernels`: %s\n" % cols)
+        if len(starts) < 6:
+            f.write("too few passes\n")
+            return
+        # a pass in the middle of the run: from its first preprocess launch to the one two launches later (two chains)
+        a, b = starts[len(starts) // 2], starts[len(starts) // 2 + 2] if len(starts) // 2 + 2 < len(starts) else len(rows)
+        t0 = rows[a][1]
+        ev = []
+        for r in rows[a:b]:
+            f.write("%9.1f %9.1f %8.1f us  q=%s  %s\n" % ((r[1] - t0) / 1e3, (r[2] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", short(r[0])[:90]))
+            if is_net(r[0]):
+                ev.append((r[1], 1))
+                ev.append((r[2], -1))
+        ev.sort()
+        lvl, last, hist = 0, None, {}
+        for t, d in ev:
+            if last is not None:
+                hist[min(lvl, 3)] = hist.get(min(lvl, 3), 0) + (t - last)
+            lvl += d
+            last = t
+        tot = sum(hist.values())
+        f.write("network kernels in flight: " + ", ".join("%d: %.1f us (%.0f%%)" % (k, v / 1e3, 100.0 * v / tot) for k, v in sorted(hist.items())) + "\n")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "mfma":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
