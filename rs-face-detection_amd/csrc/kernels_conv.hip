@@ -358,15 +358,18 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 // memory pipeline idles through every tile's prologue (address set-up, first-operand latency), epilogue (bias fetch, store
 // drain) and the workgroup relaunch: 3.1 TB/s of HBM-side traffic where the tensors need 5+.
 // Here a workgroup is PERSISTENT and X-STATIONARY: it owns a stripe of 128-pixel tiles; per tile the whole activation tile
-// [128][K] is staged once (instead of once per N tile: -25 % bytes through the CU's load path), then the weight K-steps of
-// all N / 128 output chunks stream through a 3-slot ring without a break -- across chunk and tile boundaries.  The
-// residual of chunk c+1 is requested (straight into registers, two alternating sets) BEFORE the stores of chunk c are
-// issued, bias / scale / shift sit in an LDS table, and every wait is a COUNTED s_waitcnt: the stores of chunk c drain while
-// chunk c+1's MFMAs run and chunk c+2's residual is already on its way -- the memory pipeline never sees a gap except at a
-// tile's first step.  The residual loads are inline asm (hipcc would wait vmcnt(0) at their use and drain the DMAs);
-// every output goes through a buffer store that is ALWAYS issued (out-of-range offset for rows >= M), so that the
-// operation counts the waits rely on are exact.  8 waves: 4 (pixels) x 2 (channels), 32 x 64 outputs each.
-// Per wave and chunk, in issue order:  W W (step 0) ... W W (step NK-1) | R R R R (next chunk) | S x ST.
+// [128][K] is staged once (instead of once per N tile: -25 % bytes through the CU's load path), then the chunks of 128 output
+// channels follow one another without a break.  Software pipeline, per chunk c:
+//     K-steps of c (MFMA; the weight K-steps of c+1 are issued meanwhile, one per step, a whole chunk ahead)
+//     s_waitcnt vmcnt(0)        <- the ONLY wait: stores of c-1, residual of c, weights of c+1 -- all issued >= 1 step ago
+//     epilogue of c: request the residual of c+1 (registers, two alternating sets), + bias (LDS table), store c
+// so the stores of chunk c and the residual of c+1 travel while the MFMAs of c+1 run, and what the wait really waits for
+// is the HBM pipe itself.  Every wait is a full drain on purpose: a COUNTED vmcnt is only sound when the operations that
+// must have landed cannot be overtaken by younger ones, and LDS-DMA from L2 (weights) does overtake older LDS-DMA from HBM
+// (activations) -- a first version with counted waits returned stale activation tiles in the first chunk of ~3 % of the
+// tiles (tests/test_persistent_gpu.py).  The residual loads are inline asm (hipcc would otherwise
+// place its own wait at an unknown point).  8 waves: 4 (pixels) x 2 (channels), 32 x 64 outputs each.
+// LDS: activation tile NK x 16 KiB + weight ring (NK + 1) x 16 KiB + 12 B per output channel: 156 KiB at K = 256.
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 make_srd(const void *base, uint32_t bytes)
@@ -383,11 +386,7 @@ __device__ __forceinline__ void asm_buffer_load_b128(u32x4 &dst, uint32_t voff, 
 template <int NK, bool HAS_Y, bool HAS_Y2>
 __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 {
-    constexpr int BM = 128, WSLOTS = 3, PF = 2;     // PF = weight K-steps in flight beyond the one being consumed
-    constexpr int ST = (HAS_Y ? 4 : 0) + (HAS_Y2 ? 4 : 0);
-    constexpr int N_STEP = 2 * (PF - 1);              // steady state: only the next weight step may stay in flight
-    constexpr int N_STEP_HEAD = 2 * (PF - 1) + 4 + ST; // first PF steps of a chunk: + the previous epilogue's loads and stores
-    constexpr int N_RES = ST + 2 * NK + 4;            // younger than this chunk's residual: stores, NK weight steps, next residual
+    constexpr int BM = 128, WSLOTS = NK + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);   // [NK][BM*64]
     bf16_t *Ws = Xs + NK * BM * 64;                  // [WSLOTS][128*64]
@@ -423,7 +422,7 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
         const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
         woff[q] = (uint32_t)(((size_t)chn * K + chunk * 8) * 2);
     }
-    // the weight stream: position of the NEXT step to issue (cycles through all chunks, tile after tile)
+    // the weight stream: position of the NEXT step to issue (cycles through all chunks, tile after tile), one chunk ahead
     int wi_nc = 0, wi_kt = 0, wi_slot = 0;
     auto issue_w = [&]() {
         const uint32_t so = (uint32_t)((((size_t)wi_nc * 128) * K + (wi_kt << 6)) * 2);
@@ -448,7 +447,7 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
     u32x4 resA[4], resB[4];
     issue_res(resA, blockIdx.x, 0);
 #pragma unroll
-    for (int i = 0; i < PF; ++i) issue_w();
+    for (int i = 0; i < NK; ++i) issue_w(); // the first chunk's weights
     int cslot = 0; // ring slot of the weight step consumed next
 
     for (int mt = blockIdx.x; mt < tiles_m; mt += gridDim.x) {
@@ -464,6 +463,7 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
                 blds16(rx, m < M ? (uint32_t)(((size_t)m * K + chunk * 8) * 2) : kOob, (uint32_t)(kt << 7),
                        Xs + kt * BM * 64 + (wave + 8 * q) * 512);
             }
+        wait_vmcnt<0>(); // the activation tile (this chunk's weights landed at the previous drain, or are older)
         auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4]) __attribute__((always_inline)) {
             f32x4 acc[4][2];
 #pragma unroll
@@ -472,12 +472,8 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
                 for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) {
-                // first chunk of a tile: X(kt) is younger than every weight step in flight; 2 (NK - 1) operations are
-                // younger than X(kt) at step kt (the later activation steps + the weight steps issued since).  Otherwise:
-                // W(step) was issued PF steps ago.
-                if (nc == 0) wait_vmcnt<2 * (NK - 1)>();
-                else if (kt < PF) wait_vmcnt<N_STEP_HEAD>();
-                else wait_vmcnt<N_STEP>();
+                // everything this step reads was drained by every wave before it got here; the barrier publishes it and
+                // frees the ring slot read one step ago for the matching K-step of the NEXT chunk
                 asm volatile("s_barrier" ::: "memory");
                 issue_w();
                 const bf16_t *xs = Xs + kt * BM * 64 + (wm * 32) * 64;
@@ -504,11 +500,12 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
             }
-            // ---- epilogue: the NEXT chunk's residual first (next tile's chunk 0 after the last chunk), then this one's ----
+            // ---- the one wait of the chunk: residual of this chunk, weights of the next, stores of the previous ----
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- epilogue: request the NEXT chunk's residual (next tile's chunk 0 after the last chunk), then this one's ----
             if (nc + 1 < NC) issue_res(nxt, mt, nc + 1);
             else issue_res(nxt, mt + (int)gridDim.x, 0);
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(N_RES));
-            __builtin_amdgcn_sched_barrier(0);
             const int n0 = nc << 7;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -562,7 +559,7 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
             do_chunk(nc + 1, resB, resA);
         }
     }
-    wait_vmcnt<0>(); // weight steps and residual loads issued beyond the end
+    wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
 }
 
 template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const ConvParams &p, hipStream_t s)
@@ -579,7 +576,7 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    const size_t lds = (size_t)(NK * 128 + 3 * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
+    const size_t lds = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_stream_kernel<NK, HAS_Y, HAS_Y2>), 160 * 1024));
     hipLaunchKernelGGL((pw_stream_kernel<NK, HAS_Y, HAS_Y2>), dim3(grid), dim3(512), lds, s, p);
@@ -588,6 +585,7 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
+
     if (p.y && p.y2) return launch_pw_stream<NK, true, true>(p, s);
     if (p.y) return launch_pw_stream<NK, true, false>(p, s);
     return launch_pw_stream<NK, false, true>(p, s);
@@ -826,11 +824,9 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, in
     stage_halo(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int next = tile + gridDim.x;
-        // this tile's halo (and, the first time, the filter bank) has landed in every wave; the other buffer is free.
-        // After the first tile the 4 output stores of the previous tile are the only younger operations of this wave
-        // (buffer stores, always issued: out-of-image pixels get an out-of-range offset), and they may stay in flight.
+        // this tile's halo (and, the first time, the filter bank) has landed in every wave (drained below, before the
+        // previous tile's stores were issued); the other buffer is free
         if (tile == (int)blockIdx.x) wait_vmcnt<0>();
-        else wait_vmcnt<4>();
         asm volatile("s_barrier" ::: "memory");
         if (next < ntiles) stage_halo(next, buf ^ 1);
         const bf16_t *xb = xbase + buf * (kC64HP * 512);
@@ -858,6 +854,9 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, in
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
+        // the next tile's halo (issued a whole tile ago) and the previous tile's stores: a full drain, BEFORE this tile's
+        // stores are issued -- a counted wait behind them would rest on stores never overtaking older LDS-DMA loads
+        wait_vmcnt<0>();
         // epilogue: + bias, ReLU, 16-byte stores (8 consecutive channels of one pixel per lane)
         const int b = tile / (tiles_x * tiles_y), rem = tile - b * tiles_x * tiles_y;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;

@@ -1,0 +1,66 @@
+"""The persistent kernels (pw_stream_kernel: short-K wide-N pointwise layers; conv3x3_c64_kernel: 64 -> 64 3x3 with the
+filter bank resident in LDS) against the generic implicit-GEMM kernel on the SAME inputs at batch sizes where every
+workgroup walks SEVERAL tiles (the per-op tests of test_network_gpu.py run at n = 2: one tile per workgroup) and where the
+last tile is partial.  Both paths accumulate in the same K order, so the outputs must be bit-identical; the generic
+kernel itself is checked against torch-CPU f32 in test_network_gpu.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [32, 17])
+def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
+    det = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=32, max_det=16)
+    det.init_synthetic_weights(1234)
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    rng = np.random.default_rng(n)
+    ops = []
+    for i, o in enumerate(g.ops):
+        L = g.layers[o.layer]
+        if o.kind != 2:
+            continue
+        pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (128, 256) and L.cout >= 4 * L.cin
+        c64 = L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0
+        if pw or c64:
+            ops.append(i)
+    assert len(ops) >= 10
+    checked = 0
+    for i in ops:
+        o = g.ops[i]
+        for t in (o.in_, o.res):
+            if t < 0:
+                continue
+            td = g.tensors[t]
+            x = rng.normal(0, 1, size=(n, td.height, td.width, td.channels)).astype(np.float32)
+            if t == o.in_:
+                x = np.maximum(x, 0)
+            det.debug_write(t, (x.view(np.uint32) >> 16).astype(np.uint16))
+        outs = [t for t in (o.out, o.out2) if t >= 0]
+        res = {}
+        for tile in (7, 0):
+            det.debug_set_conv_tile(tile)
+            if o.out >= 0 and o.out == o.in_:   # SSH: the op writes a channel slice of its own input tensor
+                pass
+            for rep in range(2 if tile == 0 else 1):   # twice: the persistent path must also be repeatable
+                for t in outs:
+                    if t != o.in_:
+                        td = g.tensors[t]
+                        det.debug_write(t, np.full((n, td.height, td.width, td.channels), 0x7fc0, np.uint16))  # NaN poison
+                det.debug_run(n, i, i)
+                got = [det.debug_read(t, n, g.tensors[t]) for t in outs]
+                if tile == 0 and rep == 1:
+                    for a, b in zip(got, res[0]):
+                        assert np.array_equal(a, b), "op %d: persistent kernel not repeatable" % i
+                res[tile] = got
+        for t, a, b in zip(outs, res[0], res[7]):
+            if t == o.in_:   # in-place slice writers: compare only the written channels
+                L = g.layers[o.layer]
+                a, b = a[..., o.y_coff:o.y_coff + L.cout], b[..., o.y_coff:o.y_coff + L.cout]
+            bad = int((a != b).sum())
+            assert bad == 0, "op %d (%s) tensor %d: %d / %d elements differ from the generic kernel at n = %d" % (
+                i, g.layers[o.layer].name.decode(), t, bad, a.size, n)
+            checked += 1
+    det.debug_set_conv_tile(0)
+    det.close()
+    assert checked >= 10
