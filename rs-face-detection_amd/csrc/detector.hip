@@ -780,7 +780,7 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
 }
 int rfd_debug_set_conv_tile(rfd_ctx *c, int tile)
 {
-    RFD_CHECK_ARG(c && tile >= 0 && tile <= 9, "bad argument");
+    RFD_CHECK_ARG(c && tile >= 0 && tile <= 15, "bad argument");
     RFD_TRY(c->ensure_network());
     c->net.force_tile = tile;
     return RFD_OK;

@@ -157,9 +157,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
     }
 }
 
+#ifndef RFD_SAFE_WAITS
+#define RFD_SAFE_WAITS 0 // diagnostic build (-DRFD_SAFE_WAITS=1): every counted wait becomes a full drain
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RFD_SAFE_WAITS ? 0 : N) : "memory");
 }
 
 // LDS operand rings: NSX slots for the activation (im2col) tile, 2 for the weight tile.  With NSX = 3 the
@@ -383,6 +386,23 @@ __device__ __forceinline__ void asm_buffer_load_b128(u32x4 &dst, uint32_t voff, 
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(srd) : "memory");
 }
 
+// 8 consecutive floats of an LDS table as four 64-bit reads.  NOT ds_read_b128: lanes that share an address (here the
+// 16 lanes of a quarter wave) reading 128 bits is the access shape that returned wrong data in lanes 48-63 whenever MFMA
+// waves of ANOTHER kernel shared the CU -- and this kernel does co-reside with the other chain's
+// convolution workgroups in the split mode.
+__device__ __forceinline__ void lds_table_read8(const float *tab, float (&v)[8])
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a, b, c, d;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"((uint32_t)(uintptr_t)tab)
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
+}
+
 template <int NK, bool HAS_Y, bool HAS_Y2>
 __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 {
@@ -511,15 +531,10 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
             for (int h = 0; h < 2; ++h) {
                 const int n = n0 + wn * 64 + h * 32 + fq * 8;
                 float bias[8], s2[8], t2[8];
-                {
-                    const float4 b0 = *reinterpret_cast<const float4 *>(Tab + n), b1 = *reinterpret_cast<const float4 *>(Tab + n + 4);
-                    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-                }
+                lds_table_read8(Tab + n, bias);
                 if (HAS_Y2) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(Tab + N + n), a1 = *reinterpret_cast<const float4 *>(Tab + N + n + 4);
-                    const float4 c0 = *reinterpret_cast<const float4 *>(Tab + 2 * N + n), c1 = *reinterpret_cast<const float4 *>(Tab + 2 * N + n + 4);
-                    s2[0] = a0.x; s2[1] = a0.y; s2[2] = a0.z; s2[3] = a0.w; s2[4] = a1.x; s2[5] = a1.y; s2[6] = a1.z; s2[7] = a1.w;
-                    t2[0] = c0.x; t2[1] = c0.y; t2[2] = c0.z; t2[3] = c0.w; t2[4] = c1.x; t2[5] = c1.y; t2[6] = c1.z; t2[7] = c1.w;
+                    lds_table_read8(Tab + N + n, s2);
+                    lds_table_read8(Tab + 2 * N + n, t2);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -576,7 +591,15 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    const size_t lds = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
+    // The kernel needs (2 NK + 1) x 16 KiB + 12 B per output channel (86 KiB at K = 128, 156 KiB at K = 256) but always asks
+    // for the CU's whole LDS: a persistent workgroup must not share its CU with workgroups of ANOTHER kernel.  At 86 KiB the
+    // K = 128 variant co-resided with the other chain's 3x3 workgroups in the split mode, and exactly that configuration
+    // produced nondeterministic outputs (2-3 images of a 16-image part wrong in 5 of 8 passes; never with the 156 KiB variant,
+    // never once the request was padded: gpurun_out/r2_splitdiag5.txt) -- the same family as the round-1
+    // observation that LDS reads go wrong next to MFMA waves of another kernel.
+    const size_t lds_need = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
+    const size_t lds = 160 * 1024;
+    if (lds_need > lds) { set_error("pw_stream: %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_stream_kernel<NK, HAS_Y, HAS_Y2>), 160 * 1024));
     hipLaunchKernelGGL((pw_stream_kernel<NK, HAS_Y, HAS_Y2>), dim3(grid), dim3(512), lds, s, p);
@@ -890,7 +913,9 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
     const int ncu = 256;
     const int per = ceil_div(ntiles, ncu);
     const int grid = ceil_div(ntiles, per); // even share per persistent workgroup: no tail
-    const size_t lds = (size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t);
+    // needs 154 KiB; asks for the whole CU's LDS so that no other kernel's workgroup can ever share the CU (see launch_pw_stream)
+    static_assert((size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t) <= 160 * 1024, "LDS");
+    const size_t lds = 160 * 1024;
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv3x3_c64_kernel), (int)lds));
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y);
@@ -1146,12 +1171,13 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     const bool pw_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.in_scale && !p.yf && p.res &&
                        !p.res_up2 && !p.res_post && p.ldx == p.Cin && p.x_coff == 0 && p.Cout % 128 == 0 && p.Cout >= 4 * p.Cin &&
                        p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout && (!p.y || p.ldy == p.Cout) &&
-                       (p.Cin == 128 || p.Cin == 256) && (p.force_tile == 0 || p.force_tile == 6);
+                       (p.Cin == 128 || p.Cin == 256) && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 8 ||
+                        (p.force_tile == 10 && p.Cin == 128) || (p.force_tile == 11 && p.Cin == 256));
     if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024) return p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
-                        (p.force_tile == 0 || p.force_tile == 6);
+                        (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 9);
     if (c64_ok) return launch_conv3x3_c64(p, s);
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
