@@ -20,7 +20,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
         L = g.layers[o.layer]
         if o.kind != 2:
             continue
-        pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (128, 256) and L.cout >= 4 * L.cin
+        pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin
         c64 = L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0
         if pw or c64:
             ops.append(i)
