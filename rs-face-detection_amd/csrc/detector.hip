@@ -438,6 +438,8 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
         pp.out_nhwc4 = (bf16_t *)net.tensor_ptr(net.g.input) + (size_t)off * in_px;
         status = launch_preprocess(pp, Bp, st[p]);
+        if (status == RFD_OK && p == 1 && net.chain_shift_op >= 0 && net.chain_shift_op < (int)net.g.ops.size() &&
+            hipStreamWaitEvent(st[1], net.ev_shift, 0) != hipSuccess) status = RFD_ERR_HIP;
         if (status == RFD_OK) status = net.run(Bp, st[p], 0, -1, off, p);
         if (status == RFD_OK && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
     }

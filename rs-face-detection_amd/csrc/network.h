@@ -140,6 +140,11 @@ struct Network {
     // B = 32; eager split 6.07 k), and launch gaps are hidden at these batch sizes anyway.
     hipStream_t part_stream[kMaxParts] = {}; // [0]: only the cross-call overlap mode runs part 0 off the caller's stream
     hipEvent_t ev_part_fork = nullptr, ev_part_join[kMaxParts] = {};
+    // chain phase shift: part 1 starts only after part 0 has finished op `chain_shift_op` of the same pass, so that the two
+    // chains do not run the SAME kernel class side by side (compute-bound next to compute-bound, memory-bound next to
+    // memory-bound) but stay a few ops apart; -1 = both start together
+    int chain_shift_op = -1;
+    hipEvent_t ev_shift = nullptr;
     int co_running = 0;      // set while the parts of a split pass are being enqueued
     int split_min_part = 4;  // fewest images a part may hold (B = 8: 4.02 k img/s split vs 3.86 k as one graph; B <= 6: graph wins or ties)
     int split_max_parts = 2; // parts = clamp(B / split_min_part, 1, split_max_parts)

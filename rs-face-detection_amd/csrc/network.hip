@@ -408,6 +408,8 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_)
         RFD_HIP(hipEventCreateWithFlags(&ev_part_join[hh], hipEventDisableTiming));
     }
     RFD_HIP(hipEventCreateWithFlags(&ev_part_fork, hipEventDisableTiming));
+    RFD_HIP(hipEventCreateWithFlags(&ev_shift, hipEventDisableTiming));
+    if (getenv("RFD_CHAIN_SHIFT")) chain_shift_op = atoi(getenv("RFD_CHAIN_SHIFT"));
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
     d_buffers.assign(g.buffer_bytes_per_image.size(), nullptr);
@@ -445,6 +447,8 @@ void Network::destroy()
     }
     if (ev_part_fork) (void)hipEventDestroy(ev_part_fork);
     ev_part_fork = nullptr;
+    if (ev_shift) (void)hipEventDestroy(ev_shift);
+    ev_shift = nullptr;
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (hipGraphExec_t ge : graph_exec)
         if (ge) (void)hipGraphExecDestroy(ge);
@@ -738,6 +742,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             RFD_TRY(launch_conv(p, s));
         }
         if (profiling) RFD_HIP(hipEventRecord(ev[2 * i + 1], s));
+        if (co_running && part == 0 && i == chain_shift_op) RFD_HIP(hipEventRecord(ev_shift, main_stream));
     }
     for (int bidx = 0; bidx < 2; ++bidx)
         if (forked[bidx]) { // join
@@ -787,6 +792,7 @@ int Network::split_body(int B, int P, hipStream_t s)
     for (int p = 0; p < P && st == RFD_OK; ++p) {
         const int Bp = B / P + (p < B % P ? 1 : 0);
         RFD_HIP(hipStreamWaitEvent(part_stream[p], ev_part_fork, 0));
+        if (p == 1 && P == 2 && chain_shift_op >= 0 && chain_shift_op < (int)g.ops.size()) RFD_HIP(hipStreamWaitEvent(part_stream[1], ev_shift, 0));
         st = run(Bp, part_stream[p], 0, -1, off, p);
         if (st == RFD_OK) RFD_HIP(hipEventRecord(ev_part_join[p], part_stream[p]));
         off += Bp;

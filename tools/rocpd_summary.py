@@ -39,20 +39,17 @@ def stats(path, out_csv, out_json):
         f.write("kernel,calls,total_us,avg_us,percent\n")
         for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k, c, t, t / c, 100 * t / total))
-    # per pass: union of the network class's busy intervals, and the sum of its kernel durations
-    passes, cur = [], None
-    for n, s, e in rows:
-        if "preprocess_kernel" in n:
-            cur = {"iv": [], "n": 0}
-            passes.append(cur)
-        elif cur is not None and is_net(n):
-            cur["iv"].append((s, e))
-            cur["n"] += 1
-    busy, summed, counts = [], [], []
-    for p in passes:
-        if not p["iv"]:
+    # Steady-state step = the window between two consecutive decode launches (one per detect call, in every execution
+    # mode; the stream tuner's set-up passes launch no decode, so they fall outside).  Per window: union of the network
+    # class's busy intervals (kernels of neighbouring calls overlap in the async = 2 mode, which is the point), their summed
+    # durations and launch count.  Median over the last windows of the run = the timed loop.
+    dec = [s for n, s, e in rows if "decode_kernel" in n]
+    net = [(s, e) for n, s, e in rows if is_net(n)]
+    busy, summed, counts, wall = [], [], [], []
+    for a, b in list(zip(dec, dec[1:]))[-12:]:
+        iv = sorted((max(s, a), min(e, b)) for s, e in net if e > a and s < b)
+        if not iv:
             continue
-        iv = sorted(p["iv"])
         u, (cs, ce) = 0, iv[0]
         for s, e in iv[1:]:
             if s > ce:
@@ -63,13 +60,14 @@ def stats(path, out_csv, out_json):
         u += ce - cs
         busy.append(u / 1e6)
         summed.append(sum(e - s for s, e in iv) / 1e6)
-        counts.append(p["n"])
-    mode = statistics.mode(counts)
-    sel = [i for i, c in enumerate(counts) if c == mode]
-    out = {"passes": len(busy), "launches_per_pass_mode": mode,
-           "network_busy_ms_per_pass_median": statistics.median(busy[i] for i in sel),
-           "network_kernel_time_sum_ms_per_pass_median": statistics.median(summed[i] for i in sel),
-           "note": "busy = union of the start..end intervals of the network kernels of one pass (two parts overlap)"}
+        counts.append(sum(1 for s, e in net if a <= s < b))
+        wall.append((b - a) / 1e6)
+    out = {"windows": len(busy), "launches_per_step_median": statistics.median(counts) if counts else 0,
+           "step_wall_ms_median": statistics.median(wall) if wall else None,
+           "network_busy_ms_per_step_median": statistics.median(busy) if busy else None,
+           "network_kernel_time_sum_ms_per_step_median": statistics.median(summed) if summed else None,
+           "note": "step = window between consecutive decode launches (steady state of the timed loop); busy = union of the "
+                   "start..end intervals of the network kernels inside it (the two chains and neighbouring calls overlap)"}
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out))
 
