@@ -195,15 +195,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
     bf16_t *Ws = Xs + (nk > 1 ? NSX : 1) * BM * 64;            // [2][BN*64]; one slot each for a single K step
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    // tile order inside an XCD's chunk: N fastest (neighbours share the activation tile) unless the layer's filter bank
-    // would not stay in the 4 MiB L2 next to it -- then M fastest: the weight tile stays, the activation tiles stream
-    int m0, n0;
-    if (p.m_fastest) {
-        const int tiles_m = (int)gridDim.x / tiles_n;
-        n0 = (lid / tiles_m) * BN; m0 = (lid % tiles_m) * BM;
-    } else {
-        m0 = (lid / tiles_n) * BM; n0 = (lid % tiles_n) * BN;
-    }
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
     // ---- per-lane im2col bookkeeping: lane (r = lane/8, slot = lane%8) of piece q stages LDS row
     //      R = (wave + NW*q)*8 + r, slot `slot`, which holds global chunk slot ^ r of that row.
@@ -658,15 +650,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
     const int kc_n = p.Cin >> 6, ngroups = 3 * kc_n, nk = 3 * ngroups;
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    // tile order inside an XCD's chunk: N fastest (neighbours share the activation tile) unless the layer's filter bank
-    // would not stay in the 4 MiB L2 next to it -- then M fastest: the weight tile stays, the activation tiles stream
-    int m0, n0;
-    if (p.m_fastest) {
-        const int tiles_m = (int)gridDim.x / tiles_n;
-        n0 = (lid / tiles_m) * BN; m0 = (lid % tiles_m) * BM;
-    } else {
-        m0 = (lid / tiles_n) * BM; n0 = (lid % tiles_n) * BN;
-    }
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -1166,9 +1150,8 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
     return RFD_OK;
 }
 
-int launch_conv(const ConvParams &p_in, hipStream_t s)
+int launch_conv(const ConvParams &p, hipStream_t s)
 {
-    ConvParams p = p_in;
     if (p.Cin % 64 != 0 || p.Cin2 % 64 != 0 || p.Cout % 32 != 0) {
         set_error("conv: Cin=%d must be a multiple of 64 and Cout=%d of 32", p.Cin, p.Cout);
         return RFD_ERR_INVALID_ARG;
@@ -1190,12 +1173,14 @@ int launch_conv(const ConvParams &p_in, hipStream_t s)
                        p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout && (!p.y || p.ldy == p.Cout) &&
                        (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 8 ||
                         (p.force_tile == 10 && p.Cin == 128) || (p.force_tile == 11 && p.Cin == 256));
-    if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024) return p.Cin == 64 ? launch_pw_stream_nk<1>(p, s) : (p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s));
+    // a persistent workgroup walks all N / 128 chunks of its tiles one after the other: below ~half a GPU of tiles (small
+    // batches; B = 1: 13 tiles at 40 x 40) the generic kernel's tiles_m x N / 128 independent workgroups are faster
+    if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024 && (M >= 128 * 128 || p.force_tile == 6)) return p.Cin == 64 ? launch_pw_stream_nk<1>(p, s) : (p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s));
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
                         (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 9);
-    if (c64_ok) return launch_conv3x3_c64(p, s);
+    if (c64_ok && (M >= 96 * 256 || p.force_tile == 6)) return launch_conv3x3_c64(p, s); // >= 96 tiles of 16 x 16 pixels
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
     if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);
