@@ -624,7 +624,8 @@ template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_
 // pieces -- is staged, and the three kx K-steps read their B fragments at row offsets 0 / 1 / 2; a fragment
 // whose pixel sits in image column 0 (kx = 0) or W-1 (kx = 2) would wrap into the neighbouring image row
 // and is zeroed in registers instead.  Activation pieces per three K-steps: 12 -> 5 per wave; the weight
-// tile streams as before.  K order: (ky, chunk, kx) -- only the f32 summation order differs.
+// tile streams as before.  K order: (chunk, ky, kx) -- only the f32 summation order differs from the generic kernel's
+// (ky, kx, chunk); it is the order of conv3x3_halo_kernel below, so the two give bit-identical results.
 // LDS: 2 x 20 KiB activation slots + 2 weight slots: 72 KiB at BN = 128 -> two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 template <int BN, int WAVES_M, int WAVES_N>
@@ -647,7 +648,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
     const int HW = p.H * p.W;
     const int M = p.B * HW;
     const int K = 9 * p.Cin;
-    const int kc_n = p.Cin >> 6, ngroups = 3 * kc_n, nk = 3 * ngroups;
+    const int kc_n = p.Cin >> 6, ngroups = 3 * kc_n;
     const int tiles_n = p.Cout / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
@@ -723,8 +724,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
     int ky = 0, kc = 0; // current group
     int xslot = 0, wslot = 0;
     for (int g = 0; g < ngroups; ++g) {
-        int nky = ky, nkc = kc + 1; // next group
-        if (nkc == kc_n) { nkc = 0; ++nky; }
+        int nky = ky + 1, nkc = kc; // next group: chunk-major, the order conv3x3_halo_kernel is bound to (bit-identical results)
+        if (nky == 3) { nky = 0; ++nkc; }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             // step (g, kx) needs W(this step) and X(g).  Only after the kx = 0 step are the XPE youngest DMAs
@@ -919,6 +920,229 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv3x3_c64_kernel), (int)lds));
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 with Cin >= 128 (conv2 of the stage-2 / stage-3 units, the FPN aggregation convs): the filter
+// bank no longer fits LDS, but the two things that bound the merged-kx kernel above still can be cut -- LDS-DMA pieces
+// issued per MFMA and bytes through the CU's load path.  A PERSISTENT workgroup (8 waves, the CU to itself) computes
+// 256-pixel x NWG-channel work items:
+//   * pixels: a TR x TC tile of one image (16 x 16 at W = 80; 6 full rows at W = 40); its (TR+2) x (TC+2) halo tile of ONE
+//     64-channel chunk is staged once for all nine taps (c64's layout: pixel-major, 128 B per pixel, chunk swizzle keyed
+//     on the halo column), double-buffered across chunks;
+//   * weights: one [NWG][64] tile per (chunk, tap) "unit"; a K step is 32 KiB of them -- one unit at NWG = 256 (TN = 8
+//     fragments per wave), two at NWG = 128 (TN = 4) -- in a 2-slot ring: 64 MFMAs per wave between barriers.
+// DMA pieces per 64 MFMAs per wave: 4 (weights) + ~0.6 (halo), against 11.4 in the merged-kx kernel; load-path bytes per
+// 128 x 128 outputs: 0.26x - 0.5x.
+// Waits follow the rule of DESIGN.md section 5 (drain only, and only what was issued at least a step ago), which needs the
+// two operand streams in DIFFERENT waves' counters: waves 0-3 issue only weight DMAs (next step's tile, drained at the top
+// of every step), waves 4-7 only halo DMAs (next chunk's tile, HBM-served, issued 4-9 steps before their drain).
+// Nine steps are unrolled ("superblock": one chunk at TN = 8, two chunks = 18 units at TN = 4, where step 4 straddles the
+// chunk boundary and the two halo buffers are bound to chunk parity).
+// ------------------------------------------------------------------------------------------------
+template <int TC, int TR, int TN>
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int n_items)
+{
+    constexpr int HW2 = TC + 2, HPX = (TR + 2) * HW2, HP = (HPX + 7) / 8; // halo pixels, 8-pixel DMA pieces
+    constexpr int HQ = (HP + 3) / 4;                                       // pieces per halo wave
+    constexpr int HEL = HP * 512;                                          // elements per halo buffer
+    constexpr int NWG = 32 * TN;                                           // output channels per work item
+    constexpr int U = TN == 4 ? 2 : 1;                                     // units (taps) per step
+    constexpr int WEL = U * NWG * 64;                                      // elements per weight slot
+    constexpr int WQ = NWG / 32;                                           // weight pieces per W wave and unit
+    constexpr int NPIX = TR * TC;
+    static_assert(NPIX <= 256 && NPIX > 192, "four 64-pixel wave rows");
+    static_assert((2 * HEL + 2 * WEL) * 2 + 2048 <= 160 * 1024, "LDS");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xh = reinterpret_cast<bf16_t *>(smem); // [2][HEL]
+    bf16_t *Ws = Xh + 2 * HEL;                      // [2][WEL]
+    float *Tab = reinterpret_cast<float *>(Ws + 2 * WEL); // bias[Cout <= 512]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2; // wn == 0: weight-stream waves, wn == 1: halo-stream waves
+    const int lr = lane >> 3, slot = lane & 7, frow = lane & 15, fq = lane >> 4;
+    const int K = 9 * p.Cin, KC = p.Cin >> 6;
+    const int tiles_n = p.Cout / NWG, tiles_img = tiles_x * tiles_y;
+    const int grid = gridDim.x;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)p.B * p.H * p.W * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (uint32_t)((size_t)p.B * p.H * p.W * p.ldy * 2), 0x00020000);
+    int item = xcd_remap(blockIdx.x, grid);
+    if (item >= n_items) return;
+
+    for (int c = tid; c < p.Cout; c += 512) Tab[c] = p.bias[c];
+
+    // item -> (n tile, image, tile row, tile column); n fastest: neighbouring workgroups of an XCD share the halo in L2
+    auto item_n0 = [&](int it) { return (it % tiles_n) * NWG; };
+    // ---- halo stream (waves 4-7): piece q of wave wm covers halo pixels idx = (wm + 4 q) * 8 + lr ----
+    auto issue_halo = [&](int it, int chunk, int buf) {
+        const int t = it / tiles_n, b = t / tiles_img, rem = t - b * tiles_img;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        int lr_ = lr; // opaque: the per-piece halo coordinates are recomputed here (a few VALU ops once per chunk, in the
+        asm volatile("" : "+v"(lr_)); // halo waves only) instead of living in 2 x HQ registers across the MFMA loop
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int piece = wm + 4 * q;
+            if (piece < HP) {
+                const int idx = piece * 8 + lr_, hy = idx / HW2, hx = idx - hy * HW2;
+                const int gy = ty * TR - 1 + hy, gx = tx * TC - 1 + hx;
+                const bool ok = idx < HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const uint32_t off = (uint32_t)(((((size_t)b * p.H + gy) * p.W + gx) * p.ldx + p.x_coff + ((slot ^ (hx & 7)) << 3)) * 2);
+                blds16(rx, ok ? off : kOob, (uint32_t)(chunk << 7), Xh + buf * HEL + piece * 512);
+            }
+        }
+    };
+    // ---- weight stream (waves 0-3): LDS row rho of a unit tile holds output channel perm(rho) (8 consecutive channels
+    //      per lane in the epilogue); piece q of wave wm = rows (wm + 4 q) * 8 + lr ----
+    uint32_t woff[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int rho = (wm + 4 * q) * 8 + lr;
+        const int wn_ = rho / (16 * TN), rw_ = rho % (16 * TN), i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = wn_ * 16 * TN + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        woff[q] = (uint32_t)(((size_t)chn * K + ((slot ^ lr) << 3)) * 2);
+    }
+    auto issue_w = [&](int wslot, int it, int c0, int s) { // step s of the superblock starting at chunk c0 of item it
+        const uint32_t rowbase = (uint32_t)((size_t)item_n0(it) * K * 2);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int u = s * U + k, cs = u / 9, tap = u - cs * 9;
+            const uint32_t col = (uint32_t)((tap * p.Cin + ((c0 + cs) << 6)) * 2);
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                blds16(rw, woff[q], rowbase + col, Ws + wslot * WEL + k * (NWG * 64) + (wm + 4 * q) * 512);
+        }
+    };
+
+    // ---- per-lane fragment addresses ----
+    // B fragment (j): pixel slot q = 64 wm + 16 j + frow of the tile -> (r, c); tap (ky, kx) reads halo pixel (r + ky, c + kx)
+    int xa[4][3]; // element offset inside a halo buffer of (j, kx) at ky = 0, kk = 0; kk = 1 flips chunk bit 2 (^ 32 elements)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int q = wm * 64 + j * 16 + frow;
+        if (q > NPIX - 1) q = NPIX - 1;
+        const int r = q / TC, c = q - r * TC;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) xa[j][kx] = (r * HW2 + c + kx) * 64 + ((fq ^ ((c + kx) & 7)) << 3);
+    }
+    const int wa0 = (wn * 16 * TN + frow) * 64 + (((0 * 4 + fq) ^ (frow & 7)) << 3);
+    const int wa1 = (wn * 16 * TN + frow) * 64 + (((1 * 4 + fq) ^ (frow & 7)) << 3);
+
+    f32x4 acc[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int c0 = 0, wslot = 0, hbuf = 0;
+    if (wn == 0) issue_w(0, item, 0, 0);
+    else issue_halo(item, 0, 0);
+    while (true) {
+        int nitem = item, nc0 = c0 + U;
+        if (nc0 >= KC) { nc0 = 0; nitem = item + grid; }
+        const bool has_next = nitem < n_items;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            // weights of this step were issued a step ago; a halo tile 4+ steps ago (the bias table, the first time, by plain stores)
+            if (wn == 0 || s == 0 || (U == 2 && s == 4)) wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (wn == 0) {
+                if (s < 8) issue_w(wslot ^ 1, item, c0, s + 1);
+                else if (has_next) issue_w(wslot ^ 1, nitem, nc0, 0);
+            } else if (U == 1) {
+                if (s == 0 && has_next) issue_halo(nitem, nc0, hbuf ^ 1);
+            } else {
+                if (s == 0) issue_halo(item, c0 + 1, 1);
+                if (s == 5 && has_next) issue_halo(nitem, nc0, 0);
+            }
+            const bf16_t *wsl = Ws + wslot * WEL;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int u = s * U + k, cs = u / 9, tap = u - cs * 9, ky = tap / 3, kx = tap - ky * 3;
+                const bf16_t *xb = Xh + (U == 2 ? cs : hbuf) * HEL + ky * HW2 * 64;
+                const bf16_t *wb = wsl + k * (NWG * 64);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 bfr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(xb + (xa[j][kx] ^ (kk << 5)));
+#pragma unroll
+                    for (int ih = 0; ih < TN; ih += 4) { // four A fragments at a time: register budget at TN = 8
+                        bf16x8 af[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(wb + (ih + i) * 1024 + (kk ? wa1 : wa0));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[ih + i][j], 0, 0, 0);
+                    }
+                }
+            }
+            wslot ^= 1;
+        }
+        if (nc0 == 0) {
+            // ---- epilogue of the item: drain first (next step's weights / next chunk's halo were issued >= a step ago), then
+            //      + bias, ReLU, 16-byte stores (8 consecutive channels of one pixel per lane) ----
+            wait_vmcnt<0>();
+            const int t = item / tiles_n, n0 = item_n0(item), b = t / tiles_img, rem = t - b * tiles_img;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+            for (int ip = 0; ip < TN / 2; ++ip) {
+                const int ch0 = n0 + wn * 16 * TN + ip * 32 + fq * 8;
+                float bias[8];
+                lds_table_read8(Tab + ch0, bias);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = wm * 64 + j * 16 + frow, r = q / TC, c = q - r * TC;
+                    const int oy = ty * TR + r, ox = tx * TC + c;
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[k] = acc[2 * ip][j][k] + bias[k];
+                        o[4 + k] = acc[2 * ip + 1][j][k] + bias[4 + k];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+                    }
+                    const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                    const uint32_t yoff = (uint32_t)(((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + p.y_coff + ch0) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry,
+                                                           (q < NPIX && oy < p.H && ox < p.W) ? yoff : kOob, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[2 * ip][j][k] = 0.f;
+                        acc[2 * ip + 1][j][k] = 0.f;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        item = nitem;
+        c0 = nc0;
+        if (U == 1) hbuf ^= 1;
+    }
+    wait_vmcnt<0>();
+}
+
+template <int TC, int TR, int TN> static int launch_conv3x3_halo(const ConvParams &p, hipStream_t s)
+{
+    const int tiles_x = ceil_div(p.W, TC), tiles_y = ceil_div(p.H, TR);
+    const int n_items = p.B * tiles_x * tiles_y * (p.Cout / (32 * TN));
+    const int ncu = 256;
+    const int per = ceil_div(n_items, ncu);
+    const int grid = ceil_div(n_items, per);
+    const size_t lds = 160 * 1024; // the whole CU, always: see launch_pw_stream
+    auto kern = conv3x3_halo_kernel<TC, TR, TN>;
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y, n_items);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }
@@ -1181,6 +1405,19 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
                         (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 9);
     if (c64_ok && (M >= 96 * 256 || p.force_tile == 6)) return launch_conv3x3_c64(p, s); // >= 96 tiles of 16 x 16 pixels
+    // Cin >= 128 3x3: persistent halo-tile kernel (force_tile 13 / 14: TN = 4 / 8 regardless of size; 1 / 2 / 7 opt out)
+    const bool halo_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && !p.res && !p.y2 &&
+                         !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= p.Cout && p.n_valid >= p.Cout && p.Cin % 128 == 0 &&
+                         p.Cout % 128 == 0 && p.Cout <= 512 && (p.W % 16 == 0 || p.W == 40) &&
+                         (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 13 || p.force_tile == 14);
+    if (halo_ok) {
+        const int tiles = p.W == 40 ? p.B * ceil_div(p.H, 6) : p.B * (p.W / 16) * ceil_div(p.H, 16);
+        const int items8 = p.Cout % 256 == 0 ? tiles * (p.Cout / 256) : 0, items4 = tiles * (p.Cout / 128);
+        const bool forced = p.force_tile != 0;
+        const bool use8 = p.force_tile == 14 ? items8 > 0 : (p.force_tile == 13 ? false : items8 >= 200);
+        if (use8) return p.W == 40 ? launch_conv3x3_halo<40, 6, 8>(p, s) : launch_conv3x3_halo<16, 16, 8>(p, s);
+        if (forced || items4 >= 200) return p.W == 40 ? launch_conv3x3_halo<40, 6, 4>(p, s) : launch_conv3x3_halo<16, 16, 4>(p, s);
+    }
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
     if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);

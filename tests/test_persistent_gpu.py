@@ -64,3 +64,57 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
     det.debug_set_conv_tile(0)
     det.close()
     assert checked >= 10
+
+
+def _bf16_to_f32(a):
+    return (a.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("n", [16, 5])
+def test_halo_kernel_equals_merged_kx_kernel_bitwise(rfd, n):
+    """conv3x3_halo_kernel (Cin >= 128 3x3 layers; force_tile 13: 128-channel items, 14: 256-channel items) against the
+    merged-kx kernel (7).  Both accumulate in the order (chunk, ky, kx, 32-wide MFMA step), so whichever of them the
+    size heuristic of launch_conv picks -- it depends on the batch size -- the layer's output is bit-identical: a frame's
+    detections do not depend on the batch it arrives in.  Several items per workgroup (n = 16), partial last tiles (40 x 40
+    maps), item counts below the CU count (n = 5); every variant must also be bit-repeatable."""
+    det = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=16, max_det=16)
+    det.init_synthetic_weights(4321)
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    rng = np.random.default_rng(100 + n)
+    ops = []
+    for i, o in enumerate(g.ops):
+        L = g.layers[o.layer]
+        if o.kind == 2 and L.kh == 3 and L.stride == 1 and L.cin % 128 == 0 and L.cout % 128 == 0 and L.cout <= 512 \
+                and o.layer_n2 < 0 and o.res < 0 and g.tensors[o.in_].width in (80, 40):
+            ops.append(i)
+    assert len(ops) >= 8
+    checked = 0
+    for i in ops:
+        o = g.ops[i]
+        L = g.layers[o.layer]
+        td = g.tensors[o.in_]
+        x = np.maximum(rng.normal(0, 1, size=(n, td.height, td.width, td.channels)), 0).astype(np.float32)
+        det.debug_write(o.in_, (x.view(np.uint32) >> 16).astype(np.uint16))
+        res = {}
+        tiles = (7, 13) + ((14,) if L.cout % 256 == 0 else ())
+        for tile in tiles:
+            det.debug_set_conv_tile(tile)
+            for rep in range(1 if tile == 7 else 2):
+                to = g.tensors[o.out]
+                det.debug_write(o.out, np.full((n, to.height, to.width, to.channels), 0x7fc0, np.uint16))
+                det.debug_run(n, i, i)
+                got = det.debug_read(o.out, n, to)
+                if rep == 1:
+                    assert np.array_equal(got, res[tile]), "op %d tile %d: not repeatable" % (i, tile)
+                res[tile] = got
+        want = res[7][..., o.y_coff:o.y_coff + L.cout]
+        assert not (want == 0x7fc0).any()
+        for tile in tiles[1:]:
+            got = res[tile][..., o.y_coff:o.y_coff + L.cout]
+            bad = int((got != want).sum())
+            assert bad == 0, "op %d (%s) tile %d: %d / %d elements differ from the merged-kx kernel at n = %d" % (
+                i, L.name.decode(), tile, bad, got.size, n)
+            checked += 1
+    det.debug_set_conv_tile(0)
+    det.close()
+    assert checked >= 12

@@ -35,7 +35,14 @@ for t in range(g.num_tensors):  # random bf16 activations everywhere (never benc
 det.set_profiling(True)
 for _ in range(20):  # clocks up
     det.debug_run(max(batches), 0, -1)
-ops = [int(x) for x in a.ops.split(",")] if a.ops != "all" else [k for k, o in enumerate(g.ops) if o.kind in (2, 6)]
+if a.ops == "all":
+    ops = [k for k, o in enumerate(g.ops) if o.kind in (2, 6)]
+elif a.ops == "halo":  # the layers conv3x3_halo_kernel accepts
+    ops = [k for k, o in enumerate(g.ops) if o.kind == 2 and g.layers[o.layer].kh == 3 and g.layers[o.layer].stride == 1
+           and g.layers[o.layer].cin % 128 == 0 and g.layers[o.layer].cout % 128 == 0 and g.layers[o.layer].cout <= 512
+           and o.res < 0 and o.layer_n2 < 0 and g.tensors[o.in_].width in (80, 40)]
+else:
+    ops = [int(x) for x in a.ops.split(",")]
 res = {}
 for rnd in range(a.rounds):
     for B in batches:
