@@ -131,6 +131,7 @@ struct ConvParams {
     int force_tile;       // 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tile (tuning / tests)
     int co_running;       // another chain of the same pass runs concurrently (batch split): affects the tile heuristic
     int head_softmax;     // heads: channels [0,4) are cls logits -> 2-class softmax pairs (a, A+a)
+    int k_chunk_major;    // set by launch_conv: K order (chunk, ky, kx) instead of (ky, kx, chunk) (see conv_igemm_kernel)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);
 // back-to-back fusion (stage 1): raw = conv3(x) [+ 1x1 shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw*scale+shift)) + bias1)

@@ -171,7 +171,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // activation DMAs, so a counted `s_waitcnt vmcnt(XP)` retires everything step kt needs and leaves the
 // activation tile kt+1 in flight across the barrier.  128x128: 3*16 + 2*16 = 80 KiB -> two workgroups
 // fill the CU's 160 KiB exactly.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX, bool CHUNK_MAJOR = false>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = WAVES_M * WAVES_N;
@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
             for (int q = 0; q < XP; ++q) {
                 const bool ok = (unsigned)(hi0[q] + ky) < (unsigned)p.H && (unsigned)(wi0[q] + kx) < (unsigned)p.W;
-                blds16(rx, ok ? xoff[q] + tap : kOob, (uint32_t)(kc << 7), Xs + slot * BM * 64 + (wave + NW * q) * 512);
+                blds16(rx, ok ? xoff[q] + tap : kOob, CHUNK_MAJOR ? (uint32_t)__builtin_amdgcn_readfirstlane(kc << 7) : (uint32_t)(kc << 7),
+                       Xs + slot * BM * 64 + (wave + NW * q) * 512);
             }
         } else {
 #pragma unroll
@@ -257,15 +258,30 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                 blds16(rx2, xoff2[q], (uint32_t)((kt_x - nk1) << 7), Xs + slot * BM * 64 + (wave + NW * q) * 512);
         }
         ++kt_x;
-        if (++kc == kc_n) { kc = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+        // K order: (ky, kx, chunk) as the weight rows are laid out -- or, for the layer shapes the halo-tile 3x3 kernel accepts
+        // (CHUNK_MAJOR instantiation, picked by launch_conv), chunk-major (chunk, ky, kx), the order that kernel and the merged-kx
+        // kernel are bound to: every kernel that can run such a layer gives bit-identical results, whatever batch size picked
+        // it.  A template parameter, not a runtime flag: the extra scalar state of the second order cost this kernel its
+        // register budget (scratch spills, whose reloads drain the DMA counter: 2x slower on every layer).
+        if (CHUNK_MAJOR) {
+            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; ++kc; } }
+        } else if (++kc == kc_n) {
+            kc = 0;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
     };
+    int wtap = 0, wkc = 0; // CHUNK_MAJOR: tap / chunk of the next weight tile
     auto stage_w = [&](int slot) {
+        // (readfirstlane: the value is wave-uniform, but left in a VGPR the compiler wraps every DMA in a waterfall loop)
+        const uint32_t col = CHUNK_MAJOR ? (uint32_t)__builtin_amdgcn_readfirstlane(kt_w < nk1 ? (wtap * p.Cin + (wkc << 6)) * 2 : kt_w << 7)
+                                         : (uint32_t)(kt_w << 7);
 #pragma unroll
         for (int q = 0; q < WP; ++q) {
             const int piece = wave + NW * q;
-            if (piece < BN / 8) blds16(rw, woff[q], (uint32_t)(kt_w << 7), Ws + slot * BN * 64 + piece * 512);
+            if (piece < BN / 8) blds16(rw, woff[q], col, Ws + slot * BN * 64 + piece * 512);
         }
         ++kt_w;
+        if (CHUNK_MAJOR && ++wtap == p.KH * p.KW) { wtap = 0; ++wkc; }
     };
 
     f32x4 acc[TN][TM];
@@ -942,6 +958,9 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
 // Nine steps are unrolled ("superblock": one chunk at TN = 8, two chunks = 18 units at TN = 4, where step 4 straddles the
 // chunk boundary and the two halo buffers are bound to chunk parity).
 // ------------------------------------------------------------------------------------------------
+#ifndef RFD_HALO_EXP
+#define RFD_HALO_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage): 1 no weight DMA, 2 no halo DMA, 3 neither, 4 neither + no barrier
+#endif
 template <int TC, int TR, int TN>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int n_items)
 {
@@ -1050,38 +1069,69 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, i
         for (int s = 0; s < 9; ++s) {
             // weights of this step were issued a step ago; a halo tile 4+ steps ago (the bias table, the first time, by plain stores)
             if (wn == 0 || s == 0 || (U == 2 && s == 4)) wait_vmcnt<0>();
+#if RFD_HALO_EXP != 4
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 2
             if (wn == 0) {
                 if (s < 8) issue_w(wslot ^ 1, item, c0, s + 1);
                 else if (has_next) issue_w(wslot ^ 1, nitem, nc0, 0);
-            } else if (U == 1) {
+            }
+#endif
+#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 1
+            if (wn == 1 && U == 1) {
                 if (s == 0 && has_next) issue_halo(nitem, nc0, hbuf ^ 1);
-            } else {
+            } else if (wn == 1) {
                 if (s == 0) issue_halo(item, c0 + 1, 1);
                 if (s == 5 && has_next) issue_halo(nitem, nc0, 0);
             }
+#endif
+            // ---- the step's 64 (TN = 6: 48) MFMAs as four groups, software-pipelined: the fragments of group g + 1 are read
+            //      from LDS while group g's MFMAs issue (the compiler's own order was read - wait - 4 MFMAs - read - wait ...).
+            //      group -> (unit k, 32-wide K half kk, first A fragment ih): TN = 4: (g >> 1, g & 1, 0); else (0, g >> 1, (g & 1) NA);
+            //      a group reads NA A fragments and, when it starts a new (k, kk), the four B fragments ----
             const bf16_t *wsl = Ws + wslot * WEL;
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
+            constexpr int NA = TN == 6 ? 3 : 4;
+            bf16x8 af[2][NA], bfr[2][4];
+            auto load_group = [&](int g) {
+                const int k = TN == 4 ? g >> 1 : 0, kk = TN == 4 ? g & 1 : g >> 1, ih = TN == 4 ? 0 : (g & 1) * NA;
                 const int u = s * U + k, cs = u / 9, tap = u - cs * 9, ky = tap / 3, kx = tap - ky * 3;
                 const bf16_t *xb = Xh + (U == 2 ? cs : hbuf) * HEL + ky * HW2 * 64;
                 const bf16_t *wb = wsl + k * (NWG * 64);
+                if (TN == 4 || (g & 1) == 0) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 bfr[4];
+                    for (int j = 0; j < 4; ++j)
+                        bfr[TN == 4 ? g & 1 : (g >> 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(
+                            TC == 16 ? xb + j * (HW2 * 64) + (xa[0][kx] ^ (kk << 5))  // 16-wide tile: fragment j is tile row 4 wm + j
+                                     : xb + (xa[j][kx] ^ (kk << 5)));
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(xb + (xa[j][kx] ^ (kk << 5)));
+                for (int i = 0; i < NA; ++i) af[g & 1][i] = *reinterpret_cast<const bf16x8 *>(wb + (ih + i) * 1024 + (kk ? wa1 : wa0));
+            };
+            load_group(0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NA + 4, 0); // group 0's reads, then the pipelined pattern below
 #pragma unroll
-                    for (int ih = 0; ih < TN; ih += 4) { // four A fragments at a time: register budget at TN = 8
-                        bf16x8 af[4];
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) load_group(g + 1);
+                const int ih = TN == 4 ? 0 : (g & 1) * NA, bs = TN == 4 ? g & 1 : (g >> 1) & 1;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(wb + (ih + i) * 1024 + (kk ? wa1 : wa0));
+                for (int i = 0; i < NA; ++i)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j)
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][i], bfr[bs][j], acc[ih + i][j], 0, 0, 0);
+                // pin the interleave: one LDS read per two MFMAs while there are reads of the next group, then the rest
+                if (g < 3) {
+                    constexpr int kMfma = 4 * NA;
+                    const int nrd = NA + ((TN == 4 || ((g + 1) & 1) == 0) ? 4 : 0);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[ih + i][j], 0, 0, 0);
+                    for (int r = 0; r < nrd; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
                     }
+                    if (nrd == NA) __builtin_amdgcn_sched_group_barrier(0x008, kMfma - NA, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, kMfma - NA - 4, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA, 0);
                 }
             }
             wslot ^= 1;
@@ -1092,6 +1142,8 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, i
             wait_vmcnt<0>();
             const int t = item / tiles_n, n0 = item_n0(item), b = t / tiles_img, rem = t - b * tiles_img;
             const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+            int frow_ = frow; // opaque: pixel coordinates are recomputed here, not kept (or spilled) across the MFMA loop
+            asm volatile("" : "+v"(frow_));
 #pragma unroll
             for (int ip = 0; ip < TN / 2; ++ip) {
                 const int ch0 = n0 + wn * 16 * TN + ip * 32 + fq * 8;
@@ -1099,7 +1151,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, i
                 lds_table_read8(Tab + ch0, bias);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int q = wm * 64 + j * 16 + frow, r = q / TC, c = q - r * TC;
+                    const int q = wm * 64 + j * 16 + frow_, r = q / TC, c = q - r * TC;
                     const int oy = ty * TR + r, ox = tx * TC + c;
                     float o[8];
 #pragma unroll
@@ -1112,7 +1164,8 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, i
                         for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
                     }
                     const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                    const uint32_t yoff = (uint32_t)(((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + p.y_coff + ch0) * 2);
+                    const int nd = ch0 + p.y_coff + (ch0 >= p.y_split ? p.y_split_add : 0); // two destinations, one GEMM (SSH)
+                    const uint32_t yoff = (uint32_t)(((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + nd) * 2);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry,
                                                            (q < NPIX && oy < p.H && ox < p.W) ? yoff : kOob, 0, 0);
 #pragma unroll
@@ -1356,8 +1409,8 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     return RFD_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX>
-static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX, bool CHUNK_MAJOR>
+static int launch_conv_cfg_order(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int grid = ceil_div(M, BM) * (p.Cout / BN);
@@ -1366,12 +1419,17 @@ static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
     const size_t aff_bytes = p.in_scale ? (size_t)2 * p.Cin * sizeof(float) : 0;
     // single K step: one slot each, more workgroups per CU
     const size_t lds = (nk > 1 ? full : (size_t)(BM + BN) * 64 * sizeof(bf16_t)) + aff_bytes;
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NSX>;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NSX, CHUNK_MAJOR>;
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)(full + 16384)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX> static int launch_conv_cfg(const ConvParams &p, hipStream_t s)
+{
+    return p.k_chunk_major ? launch_conv_cfg_order<BM, BN, WAVES_M, WAVES_N, NSX, true>(p, s)
+                           : launch_conv_cfg_order<BM, BN, WAVES_M, WAVES_N, NSX, false>(p, s);
 }
 
 int launch_conv(const ConvParams &p, hipStream_t s)
@@ -1391,6 +1449,16 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     }
     const int M = p.B * p.Ho * p.Wo;
     const int nk = (p.KH * p.KW * p.Cin + p.Cin2) / 64;
+    // layer shapes conv3x3_halo_kernel accepts (any size, any force_tile): all their kernels accumulate chunk-major
+    const bool halo_shape = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && !p.res && !p.y2 &&
+                            !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.n_valid >= p.Cout && p.Cin % 128 == 0 &&
+                            (p.Cout % 128 == 0 || p.Cout == 192) && p.Cout <= 512 && (p.y_split >= p.Cout || p.y_split % 8 == 0) &&
+                            (p.W % 16 == 0 || p.W == 40);
+    if (halo_shape && !p.k_chunk_major) {
+        ConvParams q = p;
+        q.k_chunk_major = 1;
+        return launch_conv(q, s);
+    }
     // short-K, wide-N pointwise layers with a residual: persistent X-stationary streaming kernel (force_tile 1 / 2 / 5 opt out)
     const bool pw_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.in_scale && !p.yf && p.res &&
                        !p.res_up2 && !p.res_post && p.ldx == p.Cin && p.x_coff == 0 && p.Cout % 128 == 0 && p.Cout >= 4 * p.Cin &&
@@ -1405,18 +1473,27 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
                         (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 9);
     if (c64_ok && (M >= 96 * 256 || p.force_tile == 6)) return launch_conv3x3_c64(p, s); // >= 96 tiles of 16 x 16 pixels
-    // Cin >= 128 3x3: persistent halo-tile kernel (force_tile 13 / 14: TN = 4 / 8 regardless of size; 1 / 2 / 7 opt out)
-    const bool halo_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && !p.res && !p.y2 &&
-                         !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= p.Cout && p.n_valid >= p.Cout && p.Cin % 128 == 0 &&
-                         p.Cout % 128 == 0 && p.Cout <= 512 && (p.W % 16 == 0 || p.W == 40) &&
-                         (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 13 || p.force_tile == 14);
+    // Cin >= 128 3x3: persistent halo-tile kernel; work items of 128 / 192 / 256 output channels (TN = 4 / 6 / 8).  Every 3x3
+    // kernel accumulates in the same order, so the choice changes no bit of the result.
+    // force_tile 13: smallest item, 14: largest item, whatever the size; 1 / 2 / 7 opt out
+    const bool halo_ok = halo_shape && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 13 || p.force_tile == 14);
     if (halo_ok) {
         const int tiles = p.W == 40 ? p.B * ceil_div(p.H, 6) : p.B * (p.W / 16) * ceil_div(p.H, 16);
-        const int items8 = p.Cout % 256 == 0 ? tiles * (p.Cout / 256) : 0, items4 = tiles * (p.Cout / 128);
         const bool forced = p.force_tile != 0;
-        const bool use8 = p.force_tile == 14 ? items8 > 0 : (p.force_tile == 13 ? false : items8 >= 200);
-        if (use8) return p.W == 40 ? launch_conv3x3_halo<40, 6, 8>(p, s) : launch_conv3x3_halo<16, 16, 8>(p, s);
-        if (forced || items4 >= 200) return p.W == 40 ? launch_conv3x3_halo<40, 6, 4>(p, s) : launch_conv3x3_halo<16, 16, 4>(p, s);
+        if (p.Cout == 192) {
+            if (forced || tiles >= 100) return p.W == 40 ? launch_conv3x3_halo<40, 6, 6>(p, s) : launch_conv3x3_halo<16, 16, 6>(p, s);
+        } else {
+            // (the 256-channel item is not instantiated for the 40-wide row tile: its per-pixel address registers next to 128
+            //  accumulators spill to scratch, and scratch reloads share the DMA counters; 128-channel items measured 5 % slower
+            //  there at B = 32 and are what the size rule picks at B = 16 anyway)
+            const int items8 = p.Cout % 256 == 0 && p.W != 40 ? tiles * (p.Cout / 256) : 0, items4 = tiles * (p.Cout / 128);
+            // 256-channel items read the halo half as often, 128-channel items fill the last round of workgroups better:
+            // 256 unless its share of busy CU-rounds is clearly lower (B = 32, 80 x 80: 800 items = 3.1 rounds vs 1600 = 6.25)
+            auto fill = [](int n) { return (double)n / (ceil_div(n, 256) * 256); };
+            const bool use8 = p.force_tile == 14 ? items8 > 0 : (p.force_tile == 13 ? false : items8 >= 200 && fill(items8) >= fill(items4) - 0.05);
+            if (use8) return launch_conv3x3_halo<16, 16, 8>(p, s);
+            if (forced || items4 >= 200) return p.W == 40 ? launch_conv3x3_halo<40, 6, 4>(p, s) : launch_conv3x3_halo<16, 16, 4>(p, s);
+        }
     }
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;

@@ -84,10 +84,11 @@ def test_halo_kernel_equals_merged_kx_kernel_bitwise(rfd, n):
     ops = []
     for i, o in enumerate(g.ops):
         L = g.layers[o.layer]
+        # (layer_n2 >= 0: the SSH conv1 + ctx1 pair, one 192-channel GEMM with two destinations -> 192-channel items)
         if o.kind == 2 and L.kh == 3 and L.stride == 1 and L.cin % 128 == 0 and L.cout % 128 == 0 and L.cout <= 512 \
-                and o.layer_n2 < 0 and o.res < 0 and g.tensors[o.in_].width in (80, 40):
+                and o.res < 0 and g.tensors[o.in_].width in (80, 40):
             ops.append(i)
-    assert len(ops) >= 8
+    assert len(ops) >= 10 and any(g.ops[i].layer_n2 >= 0 for i in ops)
     checked = 0
     for i in ops:
         o = g.ops[i]
@@ -96,7 +97,7 @@ def test_halo_kernel_equals_merged_kx_kernel_bitwise(rfd, n):
         x = np.maximum(rng.normal(0, 1, size=(n, td.height, td.width, td.channels)), 0).astype(np.float32)
         det.debug_write(o.in_, (x.view(np.uint32) >> 16).astype(np.uint16))
         res = {}
-        tiles = (7, 13) + ((14,) if L.cout % 256 == 0 else ())
+        tiles = (7, 13) + ((14,) if L.cout % 256 == 0 and td.width != 40 and o.layer_n2 < 0 else ())
         for tile in tiles:
             det.debug_set_conv_tile(tile)
             for rep in range(1 if tile == 7 else 2):
@@ -107,10 +108,10 @@ def test_halo_kernel_equals_merged_kx_kernel_bitwise(rfd, n):
                 if rep == 1:
                     assert np.array_equal(got, res[tile]), "op %d tile %d: not repeatable" % (i, tile)
                 res[tile] = got
-        want = res[7][..., o.y_coff:o.y_coff + L.cout]
-        assert not (want == 0x7fc0).any()
+        want = res[7]                                   # whole tensor: channels the op does not write keep the poison in both
+        assert not (want[..., o.y_coff:o.y_coff + L.cout] == 0x7fc0).any()
         for tile in tiles[1:]:
-            got = res[tile][..., o.y_coff:o.y_coff + L.cout]
+            got = res[tile]
             bad = int((got != want).sum())
             assert bad == 0, "op %d (%s) tile %d: %d / %d elements differ from the merged-kx kernel at n = %d" % (
                 i, L.name.decode(), tile, bad, got.size, n)
