@@ -1215,6 +1215,219 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long-K pointwise layers (conv1 of the units: K = 512 / 1024 -> N = 128 / 256): HBM-bound activation streaming (one pass
+// over 2 K bytes per pixel for N / K <= 1/4 as many output bytes).  The generic kernel keeps ONE 16-KiB activation step in
+// flight per workgroup (32 KiB per CU) and ran these layers at 2.7-3.0 TB/s.  Here a PERSISTENT workgroup owns the CU and
+// walks 256-pixel x 128-channel items with a 3-slot activation ring (32 KiB steps, two steps = 64 KiB in flight) and a
+// 2-slot weight ring, the streams in different waves' counters so that every wait is a plain drain of DMAs issued at least
+// a step earlier (rule 1):
+//   waves 0-3: weight step k + 1 (16 KiB from L2), drained at the top of every step;
+//   waves 4-5: activation steps k + 2 for even k, waves 6-7 for odd k -- each pair drains only every other step, so its
+//              tile has had two steps (HBM latency) to land.
+// The K loop runs on across items (the next item's first tiles are requested during the last steps of this one); the
+// epilogue's stores are simply queued behind the DMAs and retire with the next drain.  Same K order and MFMA sequence as
+// the generic kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_AFF> // HAS_AFF: x' = relu(x * in_scale[c] + in_shift[c]) on the operand fragments (the producer unit's BN + ReLU)
+__global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int tiles_m, int n_items)
+{
+    constexpr int BM = 256, NWG = 128, XEL = BM * 64, WEL = NWG * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem); // [3][XEL]
+    bf16_t *Ws = Xs + 3 * XEL;                      // [2][WEL]
+    float *Tab = reinterpret_cast<float *>(Ws + 2 * WEL); // bias[Cout <= 1024] | in_scale[K <= 2048] | in_shift[K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int xgrp = (wave >> 1) & 1, xsub = wave & 1; // activation-stream waves 4-7: pair (parity of the steps it serves), half
+    const int lr = lane >> 3, slot = lane & 7, frow = lane & 15, fq = lane >> 4;
+    const int M = p.B * p.H * p.W, K = p.Cin, KC = K >> 6;
+    const int tiles_n = p.Cout / NWG;
+    const int grid = gridDim.x;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (uint32_t)((size_t)M * p.ldy * 2), 0x00020000);
+    int item = xcd_remap(blockIdx.x, grid);
+    if (item >= n_items) return;
+    for (int c = tid; c < p.Cout; c += 512) Tab[c] = p.bias[c];
+    float *Sc = Tab + p.Cout;
+    if (HAS_AFF)
+        for (int c = tid; c < K; c += 512) {
+            Sc[c] = p.in_scale[c];
+            Sc[K + c] = p.in_shift[c];
+        }
+
+    // item -> (n tile fastest, m tile): the N / 128 items of one pixel tile run next to each other on one XCD and share the
+    // activation tile in its L2
+    // ---- activation stream: piece (xsub + 2 q) of a step = pixels m0 + (xsub + 2 q) * 8 + lr, 16 B per lane ----
+    const uint32_t xlane = (uint32_t)((((xsub * 8 + lr) * p.ldx) + p.x_coff + ((slot ^ lr) << 3)) * 2);
+    auto issue_x = [&](int xslot, int it, int k) {
+        const int m0 = (it / tiles_n) * BM;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int mp = m0 + (xsub + 2 * q) * 8; // first pixel of the piece: wave-uniform (M is a multiple of 8)
+            const uint32_t sb = (uint32_t)(((size_t)(m0 + 16 * q) * p.ldx) * 2 + (k << 7));
+            blds16(rx, mp < M ? xlane + sb : kOob, 0, Xs + xslot * XEL + (xsub + 2 * q) * 512);
+        }
+    };
+    // ---- weight stream: LDS row rho holds output channel perm(rho); piece (wm + 4 q) = rows (wm + 4 q) * 8 + lr ----
+    uint32_t wlane;
+    {
+        const int rho = wm * 8 + lr, i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3;
+        const int chn = fq_ * 8 + (i_ & 1) * 4 + r_; // + 32 q
+        wlane = (uint32_t)(((size_t)chn * K + ((slot ^ lr) << 3)) * 2);
+    }
+    auto issue_w = [&](int wslot, int it, int k) {
+        const uint32_t base = (uint32_t)((size_t)(it % tiles_n) * NWG * K * 2 + (k << 7));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blds16(rw, wlane, base + (uint32_t)(q * 64 * K), Ws + wslot * WEL + (wm + 4 * q) * 512);
+    };
+    auto advance = [&](int &it, int &k) {
+        if (++k == KC) { k = 0; it += grid; }
+    };
+
+    // per-lane fragment offsets (elements): B = pixel 64 wm + 16 j + frow (swizzle key frow & 7), A = row 64 wn + 16 i + frow
+    const int xb0 = (wm * 64 + frow) * 64 + ((fq ^ (frow & 7)) << 3), xb1 = xb0 ^ 32; // second 32-wide K half: chunk bit 2
+    const int wa0 = (wn * 64 + frow) * 64 + ((fq ^ (frow & 7)) << 3), wa1 = wa0 ^ 32;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: X(0) by pair 0, X(1) by pair 1, W(0)
+    int k = 0, xs = 0, ws = 0;
+    int xi_it = item, xi_k = 0;   // next activation step to request (runs two steps ahead)
+    int wi_it = item, wi_k = 0;   // next weight step to request (one step ahead)
+    if (wn == 0) issue_w(0, item, 0);
+    advance(wi_it, wi_k);
+    if (wn == 1 && xgrp == 0) issue_x(0, xi_it, xi_k);
+    advance(xi_it, xi_k);
+    if (wn == 1 && xgrp == 1 && xi_it < n_items) issue_x(1, xi_it, xi_k);
+    advance(xi_it, xi_k);
+    int xis = 2; // slot of the next activation step to request
+    while (true) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) { // KC is even: step parity == K-step parity, the pair roles are static
+            if (wn == 0 || xgrp == par) wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (wn == 0) {
+                if (wi_it < n_items) issue_w(ws ^ 1, wi_it, wi_k);
+            } else if (xgrp == par) {
+                if (xi_it < n_items) issue_x(xis, xi_it, xi_k);
+            }
+            advance(wi_it, wi_k);
+            advance(xi_it, xi_k);
+            xis = xis == 2 ? 0 : xis + 1;
+            const bf16_t *xb = Xs + xs * XEL, *wb = Ws + ws * WEL;
+            bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8 *>(xb + j * 1024 + (kk ? xb1 : xb0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024 + (kk ? wa1 : wa0));
+            }
+            if (HAS_AFF) {
+                // this lane's 8 operand elements are input channels k * 64 + kk * 32 + fq * 8 .. + 7 of one pixel (same arithmetic
+                // as the generic kernel: f32 multiply, add, max, round to bf16)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float ss[8], tt[8];
+                    lds_table_read8(Sc + k * 64 + kk * 32 + fq * 8, ss);
+                    lds_table_read8(Sc + K + k * 64 + kk * 32 + fq * 8, tt);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x8 v = bfr[kk][j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
+                        bfr[kk][j] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+            if (!HAS_AFF) {
+                // reads of the first half, then the second half's reads under the first half's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            }
+            xs = xs == 2 ? 0 : xs + 1;
+            ws ^= 1;
+            ++k;
+        }
+        if (k == KC) {
+            // ---- epilogue: + bias, ReLU, 16-byte stores; no wait -- the stores retire with the next drains ----
+            const int m0 = (item / tiles_n) * BM, n0 = (item % tiles_n) * NWG;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const int ch0 = n0 + wn * 64 + ip * 32 + fq * 8;
+                float bias[8];
+                lds_table_read8(Tab + ch0, bias);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 64 + j * 16 + frow;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = acc[2 * ip][j][e] + bias[e];
+                        o[4 + e] = acc[2 * ip + 1][j][e] + bias[4 + e];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+                    }
+                    const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                    const uint32_t yoff = (uint32_t)(((size_t)m * p.ldy + p.y_coff + ch0) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, m < M ? yoff : kOob, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * ip][j][e] = 0.f;
+                        acc[2 * ip + 1][j][e] = 0.f;
+                    }
+                }
+            }
+            k = 0;
+            item += grid;
+            if (item >= n_items) break;
+        }
+    }
+    wait_vmcnt<0>();
+}
+
+static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.H * p.W;
+    const int tiles_m = ceil_div(M, 256), n_items = tiles_m * (p.Cout / 128);
+    const int ncu = 256;
+    const int per = ceil_div(n_items, ncu);
+    const int grid = ceil_div(n_items, per);
+    const size_t lds = 160 * 1024; // 3 x 32 + 2 x 16 KiB + bias table; the whole CU, always (see launch_pw_stream)
+    if (p.in_scale) {
+        static DynLdsOnce once;
+        RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<true>), (int)lds));
+        hipLaunchKernelGGL(pw_gemm_kernel<true>, dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
+    } else {
+        static DynLdsOnce once;
+        RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<false>), (int)lds));
+        hipLaunchKernelGGL(pw_gemm_kernel<false>, dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
+    }
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Back-to-back fusion for the pre-activation units of stage 1:
 //     raw = conv3(t2) [+ shortcut(act)] + bias (+ residual)      -> HBM (the next unit's residual)
 //     a   = relu(raw * scale + shift)                             -> bf16 operand tile in LDS only
@@ -1468,6 +1681,12 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     // a persistent workgroup walks all N / 128 chunks of its tiles one after the other: below ~half a GPU of tiles (small
     // batches; B = 1: 13 tiles at 40 x 40) the generic kernel's tiles_m x N / 128 independent workgroups are faster
     if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024 && (M >= 128 * 128 || p.force_tile == 6)) return p.Cin == 64 ? launch_pw_stream_nk<1>(p, s) : (p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s));
+    // long-K pointwise layers without a residual (conv1 of the units): persistent activation-streaming kernel
+    // (force_tile 15: whatever the size; 1 / 2 / 7 opt out)
+    const bool pwg_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.res && !p.y2 && !p.yf &&
+                        p.y && p.Cin % 128 == 0 && p.Cin >= 256 && p.Cin <= 2048 && p.Cout % 128 == 0 && p.Cout <= 1024 && p.y_split >= p.Cout &&
+                        p.n_valid >= p.Cout && M % 8 == 0 && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 15);
+    if (pwg_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 128) >= 150)) return launch_pw_gemm(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&

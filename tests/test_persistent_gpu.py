@@ -1,5 +1,5 @@
-"""The persistent kernels (pw_stream_kernel: short-K wide-N pointwise layers; conv3x3_c64_kernel: 64 -> 64 3x3 with the
-filter bank resident in LDS) against the generic implicit-GEMM kernel on the SAME inputs at batch sizes where every
+"""The persistent kernels (pw_stream_kernel: short-K wide-N pointwise layers; pw_gemm_kernel: long-K pointwise layers;
+conv3x3_c64_kernel: 64 -> 64 3x3 with the filter bank resident in LDS) against the generic implicit-GEMM kernel on the SAME inputs at batch sizes where every
 workgroup walks SEVERAL tiles (the per-op tests of test_network_gpu.py run at n = 2: one tile per workgroup) and where the
 last tile is partial.  Both paths accumulate in the same K order, so the outputs must be bit-identical; the generic
 kernel itself is checked against torch-CPU f32 in test_network_gpu.py."""
@@ -22,9 +22,12 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
             continue
         pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin
         c64 = L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0
-        if pw or c64:
+        # pw_gemm_kernel: long-K pointwise layers without a residual (conv1 of the units)
+        pwg = L.kh == 1 and L.stride == 1 and o.res < 0 and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 \
+            and o.layer_b < 0 and L.cin % 128 == 0 and L.cin >= 256 and L.cout % 128 == 0 and L.cout <= 1024
+        if pw or c64 or pwg:
             ops.append(i)
-    assert len(ops) >= 10
+    assert len(ops) >= 18
     checked = 0
     for i in ops:
         o = g.ops[i]
