@@ -344,8 +344,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per forward pass of the network conv kernels (PMC, profiles/hbm_traffic_latest.json)",
-                         "kernel": "network conv kernels of one forward pass (conv_igemm / conv3x3_kx / conv3x3_c64 / pw_stream / "
-                                   "conv_b2b_s1 / stem), timed as a class: the two half-batch chains overlap",
+                         "kernel": "network conv kernels of one forward pass (conv_igemm / conv3x3_kx / conv3x3_halo / conv3x3_c64 / "
+                                   "pw_stream / pw_gemm / conv_b2b_s1 / stem), timed as a class: the two half-batch chains overlap",
                          "flops_per_pass": net_flops, "ms_per_pass": round(net_ms_med, 4),
                          "serialised": {"note": "same pass with every op on one stream, HIP events around each of the %d "
                                                 "implicit-GEMM launches (conv0/stem excluded)" % launches,

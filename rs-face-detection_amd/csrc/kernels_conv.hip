@@ -1428,6 +1428,229 @@ static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide pointwise GEMMs (N >= 512, K >= 384: conv3 + fused stride-2 shortcut of the first unit of stages 2-4, conv3 of
+// the stage-4 units, conv1 of stage 4's first unit): MFMA-heavy, and the generic 128 x 128 tile moves 32 KiB through the
+// load path and issues 8 DMA pieces per 32 MFMAs per wave.  A PERSISTENT workgroup (8 waves = 4 pixel x 2 channel, the CU
+// to itself) computes 256-pixel x 256-channel items: 64 KiB and 8 pieces per 64 MFMAs per wave.  2-slot rings for both
+// operands (2 x 32 + 2 x 32 KiB); every wave requests a quarter of the NEXT step's activation and weight tiles right
+// after the step barrier and drains its counter at the top of the next step -- everything it waits for was issued a whole
+// step (>= 64 MFMAs per wave) earlier (rule 1).  The K loop runs on across items.  Optional second K
+// segment (the 1x1 stride-2 shortcut conv over x2: a per-lane pixel gather), residual, raw + activated outputs -- the
+// generic kernel's epilogue arithmetic in the same order, and the same K order: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) pw_wide_kernel(const ConvParams p, int n_items)
+{
+    constexpr int BM = 256, NWG = 256, XEL = BM * 64, WEL = NWG * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);        // [2][XEL]
+    bf16_t *Ws = Xs + 2 * XEL;                             // [2][WEL]
+    float *Tab = reinterpret_cast<float *>(Ws + 2 * WEL); // bias (+ bias2) [Cout <= 2048] | scale2 | shift2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int lr = lane >> 3, slot = lane & 7, frow = lane & 15, fq = lane >> 4;
+    const int HoWo = p.Ho * p.Wo, M = p.B * HoWo;
+    const int K = p.Cin + p.Cin2, KC1 = p.Cin >> 6, KC = K >> 6;
+    const int tiles_n = p.Cout / NWG;
+    const int grid = gridDim.x;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.Cin2 ? p.x2 : p.x), 0, (uint32_t)(p.Cin2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (uint32_t)((size_t)p.Cout * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : p.y2, 0, (uint32_t)((size_t)M * (p.y ? p.ldy : p.Cout) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc(p.y2 ? p.y2 : p.y, 0, (uint32_t)((size_t)M * (p.y2 ? p.Cout : p.ldy) * 2), 0x00020000);
+    int item = xcd_remap(blockIdx.x, grid);
+    if (item >= n_items) return;
+    for (int c = tid; c < p.Cout; c += 512) {
+        Tab[c] = p.bias2 ? p.bias[c] + p.bias2[c] : p.bias[c];
+        if (p.y2) {
+            Tab[p.Cout + c] = p.scale2[c];
+            Tab[2 * p.Cout + c] = p.shift2[c];
+        }
+    }
+
+    // ---- operand streams: wave w requests pieces w + 8 q (q < 4) of each 32-piece tile ----
+    // activation, first segment: pixel m0 + (w + 8 q) * 8 + lr, channels 64 k ..; second: the same pixel of the stride-2 source
+    const uint32_t xlane = (uint32_t)((((wave * 8 + lr) * p.ldx) + p.x_coff + ((slot ^ lr) << 3)) * 2);
+    uint32_t x2off[4] = {kOob, kOob, kOob, kOob};
+    auto item_x2 = [&](int it) { // per item: the lane's four source pixels of the second segment
+        const int m0 = (it / tiles_n) * BM;
+        int lr_ = lr;
+        asm volatile("" : "+v"(lr_));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + (wave + 8 * q) * 8 + lr_;
+            x2off[q] = kOob;
+            if (m < M) {
+                const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                x2off[q] = (uint32_t)(((((size_t)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + ((slot ^ lr_) << 3)) * 2);
+            }
+        }
+    };
+    uint32_t wlane;
+    {
+        const int rho = wave * 8 + lr, fq_ = (rho >> 2) & 3, r_ = rho & 3;
+        const int chn = (rho >> 5) * 32 + fq_ * 8 + ((rho >> 4) & 1) * 4 + r_; // + 64 q
+        wlane = (uint32_t)(((size_t)chn * K + ((slot ^ lr) << 3)) * 2);
+    }
+    auto issue = [&](int sl, int it, int k) {
+        const int m0 = (it / tiles_n) * BM;
+        if (k < KC1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mp = m0 + (wave + 8 * q) * 8;
+                const uint32_t sb = (uint32_t)(((size_t)(m0 + 64 * q) * p.ldx) * 2 + (k << 7));
+                blds16(rx, mp < M ? xlane + sb : kOob, 0, Xs + sl * XEL + (wave + 8 * q) * 512);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blds16(rx2, x2off[q], (uint32_t)((k - KC1) << 7), Xs + sl * XEL + (wave + 8 * q) * 512);
+        }
+        const uint32_t wbase = (uint32_t)((size_t)(it % tiles_n) * NWG * K * 2 + (k << 7));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blds16(rw, wlane, wbase + (uint32_t)(q * 128 * K), Ws + sl * WEL + (wave + 8 * q) * 512);
+    };
+
+    const int xb0 = (wm * 64 + frow) * 64 + ((fq ^ (frow & 7)) << 3), xb1 = xb0 ^ 32;
+    const int wa0 = (wn * 128 + frow) * 64 + ((fq ^ (frow & 7)) << 3), wa1 = wa0 ^ 32;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int k = 0, sl = 0;
+    const int item0 = item;
+    if (p.Cin2) item_x2(item);
+    issue(0, item, 0);
+    while (true) {
+        int nit = item, nk = k + 1;
+        if (nk == KC) { nk = 0; nit = item + grid; }
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the next item's second-segment pixels: needed from its step KC1 on, so recomputed one step into the item
+        if (p.Cin2 && k == 0 && item != item0) item_x2(item);
+        if (nit < n_items) issue(sl ^ 1, nit, nk);
+        const bf16_t *xb = Xs + sl * XEL, *wb = Ws + sl * WEL;
+        bf16x8 af[2][4], bfr[2][4];
+        auto load_group = [&](int g) { // group g -> (kk = g >> 1, A fragments 4 (g & 1) ..); B fragments with the first of a kk
+            const int kk = g >> 1, ih = (g & 1) * 4;
+            if ((g & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8 *>(xb + j * 1024 + (kk ? xb1 : xb0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[g & 1][i] = *reinterpret_cast<const bf16x8 *>(wb + (ih + i) * 1024 + (kk ? wa1 : wa0));
+        };
+        load_group(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) load_group(g + 1);
+            const int ih = (g & 1) * 4, kk = g >> 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][i], bfr[kk][j], acc[ih + i][j], 0, 0, 0);
+            if (g < 3) {
+                const int nrd = 4 + (((g + 1) & 1) == 0 ? 4 : 0);
+#pragma unroll
+                for (int r = 0; r < nrd; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                if (nrd == 4) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+        }
+        sl ^= 1;
+        if (nk == 0) {
+            // ---- epilogue of the item (the generic kernel's arithmetic, in its order) ----
+            const int m0 = (item / tiles_n) * BM, n0 = (item % tiles_n) * NWG;
+            int frow_ = frow;
+            asm volatile("" : "+v"(frow_));
+#pragma unroll
+            for (int ip = 0; ip < 4; ++ip) {
+                const int ch0 = n0 + wn * 128 + ip * 32 + fq * 8;
+                uint4 rv[4];
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = m0 + wm * 64 + j * 16 + frow_;
+                        rv[j] = *reinterpret_cast<const uint4 *>(p.res + (size_t)(m < M ? m : 0) * p.Cout + ch0);
+                    }
+                }
+                float bias[8], s2[8], t2[8];
+                lds_table_read8(Tab + ch0, bias);
+                if (p.y2) {
+                    lds_table_read8(Tab + p.Cout + ch0, s2);
+                    lds_table_read8(Tab + 2 * p.Cout + ch0, t2);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 64 + j * 16 + frow_;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[2 * ip][j][e] + bias[e];
+                        v[4 + e] = acc[2 * ip + 1][j][e] + bias[4 + e];
+                        acc[2 * ip][j][e] = 0.f;
+                        acc[2 * ip + 1][j][e] = 0.f;
+                    }
+                    if (p.res) {
+                        const uint4 r4 = rv[j];
+                        const float r[8] = {bf16_bits_to_f32(r4.x & 0xffffu), bf16_bits_to_f32(r4.x >> 16), bf16_bits_to_f32(r4.y & 0xffffu),
+                                            bf16_bits_to_f32(r4.y >> 16), bf16_bits_to_f32(r4.z & 0xffffu), bf16_bits_to_f32(r4.z >> 16),
+                                            bf16_bits_to_f32(r4.w & 0xffffu), bf16_bits_to_f32(r4.w >> 16)};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    if (p.y) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = p.relu ? fmaxf(v[e], 0.f) : v[e];
+                        const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                        const uint32_t yoff = (uint32_t)(((size_t)m * p.ldy + p.y_coff + ch0) * 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, m < M ? yoff : kOob, 0, 0);
+                    }
+                    if (p.y2) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaxf(v[e] * s2[e] + t2[e], 0.f);
+                        const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                        const uint32_t yoff = (uint32_t)(((size_t)m * p.Cout + ch0) * 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry2, m < M ? yoff : kOob, 0, 0);
+                    }
+                }
+            }
+        }
+        if (nit >= n_items) break;
+        item = nit;
+        k = nk;
+    }
+    wait_vmcnt<0>();
+}
+
+static int launch_pw_wide(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int n_items = ceil_div(M, 256) * (p.Cout / 256);
+    const int ncu = 256;
+    const int per = ceil_div(n_items, ncu);
+    const int grid = ceil_div(n_items, per);
+    const size_t lds = 160 * 1024; // 4 x 32 KiB + tables; the whole CU, always (see launch_pw_stream)
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_wide_kernel), (int)lds));
+    hipLaunchKernelGGL(pw_wide_kernel, dim3(grid), dim3(512), lds, s, p, n_items);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Back-to-back fusion for the pre-activation units of stage 1:
 //     raw = conv3(t2) [+ shortcut(act)] + bias (+ residual)      -> HBM (the next unit's residual)
 //     a   = relu(raw * scale + shift)                             -> bf16 operand tile in LDS only
@@ -1687,6 +1910,13 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                         p.y && p.Cin % 128 == 0 && p.Cin >= 256 && p.Cin <= 2048 && p.Cout % 128 == 0 && p.Cout <= 1024 && p.y_split >= p.Cout &&
                         p.n_valid >= p.Cout && M % 8 == 0 && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 15);
     if (pwg_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 128) >= 150)) return launch_pw_gemm(p, s);
+    // wide pointwise GEMMs left over by the two streaming kernels (conv3 + fused shortcut of the down-sampling units, stage-4
+    // conv3): persistent 256 x 256 tiles (force_tile 12: whatever the size; 1 / 2 / 7 opt out)
+    const bool pww_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.in_scale && !p.yf && (p.y || p.y2) &&
+                        (!p.res || (!p.res_up2 && !p.res_post)) && p.Cin2 % 64 == 0 && p.Cin + p.Cin2 >= 384 && p.Cout % 256 == 0 &&
+                        p.Cout >= 512 && p.Cout <= 2048 && p.y_split >= p.Cout && p.n_valid >= p.Cout && M % 8 == 0 &&
+                        (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 12);
+    if (pww_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 256) >= 150)) return launch_pw_wide(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&

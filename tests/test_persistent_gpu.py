@@ -1,4 +1,4 @@
-"""The persistent kernels (pw_stream_kernel: short-K wide-N pointwise layers; pw_gemm_kernel: long-K pointwise layers;
+"""The persistent kernels (pw_stream_kernel: short-K wide-N pointwise layers; pw_gemm_kernel: long-K pointwise layers; pw_wide_kernel: wide pointwise GEMMs;
 conv3x3_c64_kernel: 64 -> 64 3x3 with the filter bank resident in LDS) against the generic implicit-GEMM kernel on the SAME inputs at batch sizes where every
 workgroup walks SEVERAL tiles (the per-op tests of test_network_gpu.py run at n = 2: one tile per workgroup) and where the
 last tile is partial.  Both paths accumulate in the same K order, so the outputs must be bit-identical; the generic
@@ -16,6 +16,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
     g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
     rng = np.random.default_rng(n)
     ops = []
+    wide = set()
     for i, o in enumerate(g.ops):
         L = g.layers[o.layer]
         if o.kind != 2:
@@ -25,13 +26,18 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
         # pw_gemm_kernel: long-K pointwise layers without a residual (conv1 of the units)
         pwg = L.kh == 1 and L.stride == 1 and o.res < 0 and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 \
             and o.layer_b < 0 and L.cin % 128 == 0 and L.cin >= 256 and L.cout % 128 == 0 and L.cout <= 1024
-        if pw or c64 or pwg:
+        # pw_wide_kernel: wide pointwise GEMMs (conv3 + fused stride-2 shortcut of the down-sampling units, stage-4 conv3)
+        kk = L.cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0)
+        pww = L.kh == 1 and L.stride == 1 and o.in_affine < 0 and o.outf < 0 and o.layer_b < 0 and kk >= 384 \
+            and L.cout % 256 == 0 and 512 <= L.cout <= 2048 and not o.res_up2 and not o.res_post
+        if pw or c64 or pwg or pww:
             ops.append(i)
-    assert len(ops) >= 18
+            wide.add(i) if pww else None
+    assert len(ops) >= 22 and len(wide) >= 5
     checked = 0
     for i in ops:
         o = g.ops[i]
-        for t in (o.in_, o.res):
+        for t in (o.in_, o.res, o.in2):
             if t < 0:
                 continue
             td = g.tensors[t]
@@ -41,29 +47,32 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
             det.debug_write(t, (x.view(np.uint32) >> 16).astype(np.uint16))
         outs = [t for t in (o.out, o.out2) if t >= 0]
         res = {}
-        for tile in (7, 6):   # 7: generic kernels only; 6: persistent kernels forced whatever the problem size
+        # 7: generic kernels only; 6: persistent kernels forced whatever the problem size (the first that accepts the layer);
+        # 12: pw_wide_kernel forced (layers that pw_stream / pw_gemm would take first)
+        for tile in ((7, 6, 12) if i in wide else (7, 6)):
             det.debug_set_conv_tile(tile)
             if o.out >= 0 and o.out == o.in_:   # SSH: the op writes a channel slice of its own input tensor
                 pass
-            for rep in range(2 if tile == 6 else 1):   # twice: the persistent path must also be repeatable
+            for rep in range(2 if tile != 7 else 1):   # twice: the persistent path must also be repeatable
                 for t in outs:
                     if t != o.in_:
                         td = g.tensors[t]
                         det.debug_write(t, np.full((n, td.height, td.width, td.channels), 0x7fc0, np.uint16))  # NaN poison
                 det.debug_run(n, i, i)
                 got = [det.debug_read(t, n, g.tensors[t]) for t in outs]
-                if tile == 6 and rep == 1:
-                    for a, b in zip(got, res[6]):
-                        assert np.array_equal(a, b), "op %d: persistent kernel not repeatable" % i
+                if tile != 7 and rep == 1:
+                    for a, b in zip(got, res[tile]):
+                        assert np.array_equal(a, b), "op %d tile %d: persistent kernel not repeatable" % (i, tile)
                 res[tile] = got
-        for t, a, b in zip(outs, res[6], res[7]):
-            if t == o.in_:   # in-place slice writers: compare only the written channels
-                L = g.layers[o.layer]
-                a, b = a[..., o.y_coff:o.y_coff + L.cout], b[..., o.y_coff:o.y_coff + L.cout]
-            bad = int((a != b).sum())
-            assert bad == 0, "op %d (%s) tensor %d: %d / %d elements differ from the generic kernel at n = %d" % (
-                i, g.layers[o.layer].name.decode(), t, bad, a.size, n)
-            checked += 1
+        for tile in [t for t in res if t != 7]:
+            for t, a, b in zip(outs, res[tile], res[7]):
+                if t == o.in_:   # in-place slice writers: compare only the written channels
+                    L = g.layers[o.layer]
+                    a, b = a[..., o.y_coff:o.y_coff + L.cout], b[..., o.y_coff:o.y_coff + L.cout]
+                bad = int((a != b).sum())
+                assert bad == 0, "op %d (%s) tile %d tensor %d: %d / %d elements differ from the generic kernel at n = %d" % (
+                    i, g.layers[o.layer].name.decode(), tile, t, bad, a.size, n)
+                checked += 1
     det.debug_set_conv_tile(0)
     det.close()
     assert checked >= 10

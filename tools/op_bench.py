@@ -45,6 +45,11 @@ elif a.ops == "pwg":  # the layers pw_gemm_kernel accepts
     ops = [k for k, o in enumerate(g.ops) if o.kind == 2 and g.layers[o.layer].kh == 1 and g.layers[o.layer].stride == 1 and o.res < 0
            and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 and g.layers[o.layer].cin % 128 == 0
            and g.layers[o.layer].cin >= 256 and g.layers[o.layer].cout % 128 == 0 and g.layers[o.layer].cout <= 1024]
+elif a.ops == "pww":  # the layers pw_wide_kernel accepts
+    ops = [k for k, o in enumerate(g.ops) if o.kind == 2 and g.layers[o.layer].kh == 1 and g.layers[o.layer].stride == 1
+           and o.in_affine < 0 and o.outf < 0 and not o.res_up2 and not o.res_post and g.layers[o.layer].cout % 256 == 0
+           and 512 <= g.layers[o.layer].cout <= 2048
+           and g.layers[o.layer].cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0) >= 384]
 else:
     ops = [int(x) for x in a.ops.split(",")]
 res = {}
