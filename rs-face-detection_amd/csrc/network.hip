@@ -80,6 +80,9 @@ void Graph::build_r50()
         ops.push_back(o);
     }
     static const int units[4] = {3, 4, 6, 3};
+    // number of leading stages whose middle units hand over only the raw sum (see fuse_act below); RFD_FUSE_ACT_STAGES: A/B knob
+    int fuse_act_stages = 3;
+    if (const char *e = getenv("RFD_FUSE_ACT_STAGES")) fuse_act_stages = atoi(e);
     static const int mids[4] = {64, 128, 256, 512};
     int x_act = t_p, x_raw = -1, cin = 64, h = H / 4, w = W / 4;
     int prev_l3 = -1; // conv3 layer of the previous unit when its BN+ReLU output was NOT materialised
@@ -117,10 +120,11 @@ void Graph::build_r50()
                 ls = add_layer(nm, cin, cout, 1, stride, 0, 1.0f, 0, 0, l3, mid);
             }
             const bool last = u + 1 == units[s];
-            // Stages 1-2 (huge, memory-bound tensors): only stage outputs materialise BN+ReLU, the units in
-            // between hand over the raw sum alone.  Stages 3-4 (K >= 1024 conv1s, compute-bound): applying the
-            // affine in the consumer costs more VALU than the store it saves (measured), so both are written.
-            const bool fuse_act = s < 2;
+            // Stages 1-3: only stage outputs materialise BN+ReLU, the units in between hand over the raw sum alone and the next
+            // conv1 applies the affine to its operand fragments.  (Round 1 measured that as a loss for stage 3 with the generic
+            // kernel; with the HBM-bound streaming kernels of round 2 -- pw_stream without the second output, pw_gemm<true> --
+            // it is +1-2 % end to end: 7.24 k vs 7.09-7.19 k img/s on one box.  Stage 4 too: 7.13-7.18 k, so it keeps both.)
+            const bool fuse_act = s < fuse_act_stages;
             const int t_raw = last ? -1 : add_tensor(cout, ho, wo);
             const int t_act = (last || !fuse_act) ? add_tensor(cout, ho, wo) : -1;
             const int o3 = add_conv(l3, t2, t_raw, 0, dim_match ? x_raw : -1, t_act);
