@@ -176,6 +176,9 @@ struct rfd_ctx {
     bool net_created = false;
     // device state sized for max_batch_size
     DevBuf staging, imgs, in4, rows, keys, sorted_keys, sorted_boxes, count, det_scale;
+    DevBuf nms_kept, nms_state; // chunked NMS (dense crowds): kept-box lists, per-chunk {count, epoch} + the spin_fail word
+    int nms_epoch = 0;
+    bool nms_chunked = true; // RFD_NMS_CHUNKED=0: one workgroup per image always (A/B and fallback)
     DevBuf out_boxes, out_lmk, out_count, out_total, out_gidx;
     DevBuf scratch[12];
     DevBuf sel_dims, sel_out;
@@ -237,6 +240,9 @@ int ctx_alloc(rfd_ctx *c)
     RFD_TRY(c->keys.reserve(B * NA * sizeof(uint64_t)));
     RFD_TRY(c->sorted_keys.reserve(B * NA * sizeof(uint64_t)));
     RFD_TRY(c->sorted_boxes.reserve(B * NA * sizeof(float4)));
+    RFD_TRY(c->nms_kept.reserve(B * NA * sizeof(float4)));
+    RFD_TRY(c->nms_state.reserve((B * kNmsChunks * 2 + 1) * sizeof(int)));
+    RFD_HIP(hipMemset(c->nms_state.p, 0, (B * kNmsChunks * 2 + 1) * sizeof(int)));
     RFD_TRY(c->count.reserve(B * sizeof(int)));
     RFD_TRY(c->det_scale.reserve(B * sizeof(float)));
     RFD_TRY(c->out_boxes.reserve(B * MD * 5 * sizeof(float)));
@@ -338,6 +344,13 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
     np.max_det = c->cfg.max_det;
     np.iou_thr = c->cfg.iou_threshold;
     np.out_boxes = oboxes; np.out_lmk = olmk; np.out_count = ocount; np.out_total = ototal; np.out_gidx = ogidx;
+    if (c->nms_chunked) { // kNmsChunks workgroups per image; images with few candidates are done by the first alone
+        np.kept_boxes = (float4 *)c->nms_kept.p;
+        np.chunk_state = (int *)c->nms_state.p;
+        np.spin_fail = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
+        c->nms_epoch = c->nms_epoch == 0x7fffffff ? 1 : c->nms_epoch + 1;
+        np.epoch = c->nms_epoch;
+    }
     RFD_TRY(launch_nms(np, n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[6], c->stream));
     return RFD_OK;
@@ -559,6 +572,7 @@ int rfd_create(const rfd_config *cfg, rfd_ctx **out)
     }
     rfd_ctx *c = new rfd_ctx();
     c->cfg = *cfg;
+    if (const char *e = getenv("RFD_NMS_CHUNKED")) c->nms_chunked = atoi(e) != 0;
     make_base_anchors(c->base_anchor);
     int off = 0;
     for (int l = 0; l < kNumLevels; ++l) {
@@ -599,7 +613,7 @@ void rfd_destroy(rfd_ctx *c)
     if (c->net_created) c->net.destroy();
     DevBuf *bufs[] = {&c->staging, &c->imgs, &c->in4, &c->rows, &c->keys, &c->sorted_keys, &c->sorted_boxes,
                       &c->count, &c->det_scale, &c->out_boxes, &c->out_lmk, &c->out_count, &c->out_total,
-                      &c->out_gidx};
+                      &c->out_gidx, &c->nms_kept, &c->nms_state};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->scratch) b.release();
     c->sel_dims.release(); c->sel_out.release();

@@ -62,7 +62,13 @@ struct NmsParams {
     int *out_count;              // [n]
     int *out_total;              // [n]
     int *out_gidx;               // [n][max_det] or null
+    // chunked kernel (dense crowds: kNmsChunks workgroups per image; all null / 0: one workgroup per image)
+    float4 *kept_boxes;          // [n][total_anchors] scratch: the kept boxes of an image in score order, chunk after chunk
+    int *chunk_state;            // [n][kNmsChunks][2]: {kept count, epoch of the launch that published it}; zero-initialised once
+    int *spin_fail;              // set to 1 if a chunk gave up waiting for its predecessor (bounded spin; never expected)
+    int epoch;                   // > 0, different for every launch that uses chunk_state
 };
+constexpr int kNmsChunks = 4;
 int launch_nms(NmsParams p, int n_images, hipStream_t s);
 
 // FaceSelection::call on the device (face_selection.rs:72-189): per image, over its kept detections

@@ -425,6 +425,258 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense crowds (BASELINE.json configs[4]: ~12 k candidates, ~2 k faces per image): one workgroup per image is VALU-bound
+// (every later candidate against every kept box: 64 of 256 CUs busy for 4 ms at B = 64).  Greedy NMS is sequential in score
+// order, but only through the KEPT boxes: the sorted list is cut into kNmsChunks runs of tiles, one workgroup each.
+// Chunk c
+//   A. waits for chunks 0 .. c-1 one after the other (a flag per chunk in global memory, release / acquire at device scope)
+//      and tests its own candidates against their published kept boxes -- independent work, it overlaps the predecessors'
+//      own NMS except for the last of them;
+//   B. runs the tile loop of nms_kernel on what is left of its own run of tiles;
+//   C. appends its kept boxes to the image's list, publishes the count, emits its rows behind the earlier chunks' rows.
+// The critical path is the sum of the chunks' INTERNAL loops, each over a quarter of the tiles with a quarter of the words
+// to scan per tile.  The result is the same greedy sequence: a candidate is tested against exactly the kept boxes that
+// precede it in score order, with the same f32 arithmetic.
+// Deadlock: a workgroup waits only for workgroups of LOWER blockIdx of the same launch, which the dispatcher has started
+// before it; the spin is bounded anyway (spin_fail).  Images with few candidates (<= kNmsChunkMin) are done by chunk 0 alone.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNmsChunkMin = 2048;
+// bitmap words a wave owns in registers: a chunk has at most ceil(272 / kNmsChunks) = 68 tiles (17408 candidates), an unsplit
+// image kNmsChunkMin / 64 = 32
+constexpr int kNmsChunkWords = (((kNmsRegCap / 64 + kNmsChunks - 1) / kNmsChunks) + kNmsWaves - 1) / kNmsWaves;
+static_assert(kNmsChunkMin / 64 <= kNmsChunkWords * kNmsWaves, "unsplit images must fit the chunk kernel's registers");
+__global__ void __launch_bounds__(kNmsThreads) nms_chunked_kernel(NmsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *tile_boxes = reinterpret_cast<float4 *>(smem);                    // [64]
+    uint64_t *removed = reinterpret_cast<uint64_t *>(tile_boxes + 64);        // [nwords_cap] (local word index)
+    uint64_t *keptw = removed + p.nwords_cap;                                 // [nwords_cap]
+    int *obase = reinterpret_cast<int *>(keptw + p.nwords_cap);               // [nwords_cap]
+    uint64_t *kept_word = reinterpret_cast<uint64_t *>(obase + p.nwords_cap); // [2]
+
+    const int b = blockIdx.x / kNmsChunks, c = blockIdx.x % kNmsChunks;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.count[b];
+    const int ntiles = (n + 63) >> 6;
+    const bool split = n > kNmsChunkMin;
+    if (!split && c > 0) return;
+    const int tpc = split ? (ntiles + kNmsChunks - 1) / kNmsChunks : ntiles;
+    const int t0 = c * tpc, t1 = min(ntiles, t0 + tpc), nloc = t1 - t0;
+    if (split && nloc <= 0) return; // empty tail chunk: nobody waits for it
+    const float4 *sb = p.sorted_boxes + (size_t)b * p.total_anchors;
+    float4 *kb = p.kept_boxes + (size_t)b * p.total_anchors;
+    const float thresh = p.iou_thr;
+
+    for (int lw = tid; lw < nloc; lw += kNmsThreads) {
+        const int rem = n - (t0 + lw) * 64;
+        removed[lw] = rem >= 64 ? 0ull : ~((1ull << rem) - 1ull); // slots >= n are dead
+        keptw[lw] = 0ull;
+    }
+    float4 mybox[kNmsChunkWords]; // local word lw = wave + 16 k
+#pragma unroll
+    for (int k = 0; k < kNmsChunkWords; ++k) {
+        const int j = (t0 + wave + k * kNmsWaves) * 64 + lane;
+        mybox[k] = (wave + k * kNmsWaves < nloc && j < n) ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const uint32_t tile_base = (uint32_t)(uintptr_t)tile_boxes;
+    float myarea[kNmsChunkWords];
+#pragma unroll
+    for (int k = 0; k < kNmsChunkWords; ++k) myarea[k] = box_area(mybox[k]);
+    // Test this wave's words lw > lw_min against the kept boxes `kmask` of tile_boxes.  Kept box OUTER, the (at most five)
+    // words inner: one LDS broadcast per kept box instead of one per (kept box, word) pair, the words' boxes and areas in
+    // registers -- the loop is VALU-bound, not LDS-latency-bound.  Every wave owns whole bitmap words: one ballot, one plain LDS
+    // store per word, no atomics (as nms_kernel).
+    auto scan_words = [&](int lw_min, uint64_t kmask) {
+        uint32_t act = 0; // wave-uniform: words still to be scanned
+#pragma unroll
+        for (int k = 0; k < kNmsChunkWords; ++k) {
+            const int lw = wave + k * kNmsWaves;
+            if (lw > lw_min && lw < nloc) {
+                const uint64_t rw = removed[lw];
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rw);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rw >> 32));
+                if ((lo & hi) != 0xffffffffu) act |= 1u << k;
+            }
+        }
+        if (act == 0u) return;
+        uint32_t supb = 0; // bit k: this lane's candidate of word k is suppressed
+        uint64_t km = kmask;
+        while (km != 0ull) {
+            const int i = __builtin_ctzll(km);
+            km &= km - 1ull;
+            const float4 bi = lds_box_2x64(tile_base + (uint32_t)i * 16u);
+            const float area_i = box_area(bi);
+#pragma unroll
+            for (int k = 0; k < kNmsChunkWords; ++k)
+                if (act & (1u << k)) supb |= (uint32_t)suppresses(bi, area_i, mybox[k], myarea[k], thresh) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < kNmsChunkWords; ++k)
+            if (act & (1u << k)) {
+                const int lw = wave + k * kNmsWaves;
+                const uint64_t rw = removed[lw];
+                const uint64_t bal = __ballot((supb >> k) & 1u);
+                if (lane == 0 && (bal & ~rw) != 0ull) removed[lw] = rw | bal;
+            }
+    };
+
+    // ---- A: the kept boxes of the earlier chunks, in order, AS THEY ARE PUBLISHED (a chunk appends the kept boxes of every
+    //      tile it resolves and advances its progress word {epoch : 32 | done : 1 | count : 31}) ----
+    unsigned long long *prog = reinterpret_cast<unsigned long long *>(p.chunk_state) + (size_t)b * kNmsChunks;
+    int *sh = reinterpret_cast<int *>(kept_word); // [0] kept boxes available, [1] predecessor done (between barriers)
+    int off = 0;
+    for (int e = 0; e < c; ++e) {
+        int consumed = 0;
+        while (true) {
+            if (tid == 0) {
+                int it = 0, avail = 0, done = 0;
+                while (true) {
+                    const unsigned long long v = __hip_atomic_load(&prog[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v >> 32) == p.epoch) {
+                        avail = (int)(v & 0x7fffffffull);
+                        done = (int)((v >> 31) & 1ull);
+                    }
+                    if (avail > consumed || done) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++it > (1 << 22)) { *p.spin_fail = 1; done = 1; break; }
+                }
+                sh[0] = avail;
+                sh[1] = done;
+            }
+            __syncthreads();
+            (void)__hip_atomic_load(&prog[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); // every wave: see the boxes
+            const int avail = sh[0], done = sh[1];
+            while (consumed < avail) {
+                const int nb = min(64, avail - consumed);
+                if (tid < 64) tile_boxes[tid] = tid < nb ? kb[off + consumed + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+                __syncthreads();
+                scan_words(-1, nb >= 64 ? ~0ull : (1ull << nb) - 1ull);
+                __syncthreads();
+                consumed += nb;
+            }
+            __syncthreads(); // sh is rewritten by the next poll
+            if (done) break;
+        }
+        off += consumed;
+    }
+
+    // ---- B: the tile loop of nms_kernel<true> over this chunk's tiles (local word index lt) ----
+    const bool publish = split && t1 < ntiles; // somebody follows
+    int npub = 0;                               // kept boxes of this chunk published so far (wave-uniform, same in every wave)
+    for (int lt = 0; lt < nloc; ++lt) {
+        const int owner = lt & (kNmsWaves - 1);
+        if (wave == owner) {
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kk = lt / kNmsWaves; // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kNmsChunkWords; ++k)
+                if (k == kk) box = mybox[k];
+            const float area = box_area(box);
+            tile_boxes[lane] = box;
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t rem_t = removed[lt];
+            const uint64_t alive0 =
+                ~(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem_t >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_t));
+            uint64_t kept = 0;
+            if (alive0 != 0ull) {
+                uint64_t mask = 0;
+                uint64_t cand = alive0;
+                while (cand != 0ull) {
+                    const int jj = __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    const float4 other = lane_box(box, jj);
+                    if (jj > lane && suppresses(box, area, other, box_area(other), thresh)) mask |= 1ull << jj;
+                }
+                uint64_t alive = alive0;
+                while (alive != 0ull) {
+                    const int i = __builtin_ctzll(alive);
+                    kept |= 1ull << i;
+                    const uint32_t mlo = __builtin_amdgcn_readlane((int)(uint32_t)mask, i);
+                    const uint32_t mhi = __builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), i);
+                    const uint64_t mi = ((uint64_t)mhi << 32) | mlo;
+                    alive &= ~(mi | (1ull << i));
+                }
+            }
+            if (lane == 0) { kept_word[0] = kept; keptw[lt] = kept; }
+            if (publish) { // append this tile's kept boxes to the image's list and let the later chunks see them
+                const int nk = __builtin_popcountll(kept);
+                if ((kept >> lane) & 1ull) kb[off + npub + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = box;
+                npub += nk;
+                if (nk > 0 || lt + 1 == nloc) {
+                    __threadfence();
+                    if (lane == 0)
+                        __hip_atomic_store(&prog[c], ((unsigned long long)(unsigned)p.epoch << 32) |
+                                                         (lt + 1 == nloc ? 0x80000000ull : 0ull) | (unsigned long long)npub,
+                                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+        const uint64_t kmask = kept_word[0];
+        if (publish && wave != owner) npub += __builtin_popcountll(kmask); // every wave tracks the published count
+        if (kmask != 0ull) scan_words(lt, kmask);
+        __syncthreads();
+    }
+
+    // ---- C: exclusive prefix of the per-word kept counts (wave 0), the chunk's kept boxes appended to the image's list ----
+    if (wave == 0) {
+        const int per = (nloc + 63) >> 6;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) {
+            const int lw = lane * per + k;
+            if (lw < nloc) sum += __builtin_popcountll(keptw[lw]);
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        int run = incl - sum;
+        for (int k = 0; k < per; ++k) {
+            const int lw = lane * per + k;
+            if (lw < nloc) { obase[lw] = run; run += __builtin_popcountll(keptw[lw]); }
+        }
+        if (lane == 63) {
+            kept_word[1] = (uint64_t)incl; // the chunk's kept count
+            if (t1 == ntiles) {            // the chunk that ends the list knows the image's total
+                if (p.out_total) p.out_total[b] = off + incl;
+                if (p.out_count) p.out_count[b] = min(off + incl, p.max_det);
+            }
+        }
+    }
+    __syncthreads();
+    const int jlo = t0 * 64, jhi = min(n, t1 * 64);
+    // ---- emit the kept rows in score order behind the earlier chunks' (face_detection.rs:433-464, :473-493) ----
+    for (int j = jlo + tid; j < jhi; j += kNmsThreads) {
+        const int lw = (j >> 6) - t0;
+        const uint64_t kw = keptw[lw];
+        if (!((kw >> (j & 63)) & 1ull)) continue;
+        const int o = off + obase[lw] + __builtin_popcountll(kw & ((1ull << (j & 63)) - 1ull));
+        if (o >= p.max_det) continue;
+        uint32_t g = (uint32_t)j;
+        if (p.rows) {
+            g = (uint32_t)p.sorted_keys[(size_t)b * p.total_anchors + j];
+            float *ob = p.out_boxes + ((size_t)b * p.max_det + o) * 5;
+            const float4 *row = reinterpret_cast<const float4 *>(p.rows + ((size_t)b * p.total_anchors + g) * kDetRow);
+            const float sc = p.det_scale[b];
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            ob[0] = r0.x / sc; ob[1] = r0.y / sc; ob[2] = r0.z / sc; ob[3] = r0.w / sc;
+            ob[4] = r1.x;
+            float *ol = p.out_lmk + ((size_t)b * p.max_det + o) * 10;
+            ol[0] = r1.y / sc; ol[1] = r1.z / sc; ol[2] = r1.w / sc;
+            ol[3] = r2.x / sc; ol[4] = r2.y / sc; ol[5] = r2.z / sc; ol[6] = r2.w / sc;
+            ol[7] = r3.x / sc; ol[8] = r3.y / sc; ol[9] = r3.z / sc;
+        }
+        if (p.out_gidx) p.out_gidx[(size_t)b * p.max_det + o] = (int)g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FaceSelection::call (reference src/pipeline/module/face_selection.rs:72-189) as
 // an optional device epilogue: one thread per image walks that image's kept rows in the reference's loop
 // order (strict `>` keeps the first maximum; the key points are those of the first row within 2 px of
@@ -527,7 +779,9 @@ int launch_nms(NmsParams p, int n_images, hipStream_t s)
     static DynLdsOnce once_stream, once_reg;
     RFD_TRY(once_stream.ensure(reinterpret_cast<const void *>(nms_kernel<false>), 160 * 1024));
     RFD_TRY(once_reg.ensure(reinterpret_cast<const void *>(nms_kernel<true>), 160 * 1024));
-    if (reg) hipLaunchKernelGGL(nms_kernel<true>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
+    if (reg && p.kept_boxes && p.chunk_state && p.spin_fail && p.epoch > 0 && p.presorted_n < 0)
+        hipLaunchKernelGGL(nms_chunked_kernel, dim3(n_images * kNmsChunks), dim3(kNmsThreads), lds, s, p);
+    else if (reg) hipLaunchKernelGGL(nms_kernel<true>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     else hipLaunchKernelGGL(nms_kernel<false>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;

@@ -53,6 +53,27 @@ def test_dense_crowd(rfd, oracle, det640):
     assert exact >= 0.9999 * total
 
 
+def test_mixed_batch_dense_and_sparse_images(rfd, oracle):
+    """One launch, eight images: dense crowds (split over kNmsChunks workgroups that hand kept boxes to each other through
+    global memory), sparse images (done by the first workgroup alone, the others exit) and an empty one, twice in a row
+    (the progress words of the first launch must not satisfy the second: they carry the launch's epoch)."""
+    d = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=8, max_det=16800)
+    dense = helpers.make_heads(31, 4, cand_rate=0.25, n_faces=500)
+    sparse = helpers.make_heads(32, 3, cand_rate=0.01, n_faces=10)
+    empty = helpers.make_heads(33, 1, cand_rate=0.0)
+    order = [("d", 0), ("s", 0), ("d", 1), ("e", 0), ("d", 2), ("s", 1), ("s", 2), ("d", 3)]
+    src = {"d": dense, "s": sparse, "e": empty}
+    heads = [np.stack([src[k][l][i] for k, i in order]) for l in range(9)]
+    sc = np.linspace(0.3, 1.0, 8).astype(np.float32)
+    for _ in range(2):
+        _compare(oracle, d, heads, 8, 640, 640, sc)
+    # the reverse order: different images land on different chunk workgroups
+    heads_r = [h[::-1].copy() for h in heads]
+    _compare(oracle, d, heads_r, 8, 640, 640, sc)
+    assert d.stats()["candidates"] > 4 * 2048
+    d.close()
+
+
 def test_worst_case_all_anchors(rfd, oracle, det640):
     heads = helpers.make_heads(13, 1, cand_rate=1.0)
     _compare(oracle, det640, heads, 1, 640, 640, np.array([1.0], np.float32))
