@@ -22,6 +22,37 @@ def tbytes(t, ch=None):
     return (ch if ch else T.channels) * T.height * T.width * (4 if T.is_f32 else 2) * B
 
 
+BC = 16  # images per chain in the timed (split) mode: the size rules of launch_conv() see this batch
+
+
+def conv_class(o, L, n_out):
+    """The kernel launch_conv() picks for this op at BC images (mirrors its order of tests)."""
+    tin = g.tensors[o.in_]
+    tout = g.tensors[o.out if o.out >= 0 else (o.out2 if o.out2 >= 0 else o.outf)]
+    M = BC * tout.height * tout.width
+    plain_out = o.outf < 0 and o.layer_b < 0
+    if L.kh == 1 and L.stride == 1 and o.res >= 0 and o.layer2 < 0 and o.in_affine < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin \
+            and L.cout <= 1024 and not o.res_up2 and not o.res_post and plain_out and M >= 128 * 128:
+        return "rfd::pw_stream_kernel"
+    if L.kh == 1 and L.stride == 1 and o.res < 0 and o.layer2 < 0 and o.out2 < 0 and plain_out and L.cin % 128 == 0 and 256 <= L.cin <= 2048 \
+            and L.cout % 128 == 0 and L.cout <= 1024 and -(-M // 256) * (L.cout // 128) >= 150:
+        return "rfd::pw_gemm_kernel"
+    kk = L.cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0)
+    if L.kh == 1 and L.stride == 1 and o.in_affine < 0 and plain_out and kk >= 384 and L.cout % 256 == 0 and 512 <= L.cout <= 2048 \
+            and not o.res_up2 and not o.res_post and -(-M // 256) * (L.cout // 256) >= 150:
+        return "rfd::pw_wide_kernel"
+    if L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0 and M >= 96 * 256:
+        return "rfd::conv3x3_c64_kernel"
+    if L.kh == 3 and L.stride == 1 and L.cin % 128 == 0 and (n_out % 128 == 0 or n_out == 192) and n_out <= 512 and o.res < 0 \
+            and (tin.width % 16 == 0 or tin.width == 40):
+        tiles = BC * (-(-tin.height // 6) if tin.width == 40 else (tin.width // 16) * -(-tin.height // 16))
+        if (n_out == 192 and tiles >= 100) or (n_out != 192 and tiles * (n_out // 128) >= 200):
+            return "rfd::conv3x3_halo_kernel"
+    if L.kh == 3 and L.stride == 1 and n_out % 128 == 0 and o.layer2 < 0:
+        return "rfd::conv3x3_kx_kernel"
+    return "rfd::conv_igemm_kernel"
+
+
 cls = {}
 for i, o in enumerate(g.ops):
     L = g.layers[o.layer]
@@ -32,14 +63,8 @@ for i, o in enumerate(g.ops):
         k = "rfd::conv_b2b_s1_kernel"
     elif o.kind != 2:
         continue
-    elif L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin:
-        k = "rfd::pw_stream_kernel"
-    elif L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0:
-        k = "rfd::conv3x3_c64_kernel"
-    elif L.kh == 3 and L.stride == 1 and n_out % 128 == 0 and o.layer2 < 0:
-        k = "rfd::conv3x3_kx_kernel"
     else:
-        k = "rfd::conv_igemm_kernel"
+        k = conv_class(o, L, n_out)
     rd = tbytes(o.in_, max(L.cin, 64) if (o.kind == 2 and g.tensors[o.in_].channels > max(L.cin, 64)) else None) + tbytes(o.in2) + tbytes(o.res)
     wr = 0
     for t in (o.out, o.out2, o.outf, o.out_b):
