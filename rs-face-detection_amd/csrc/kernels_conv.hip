@@ -1904,19 +1904,20 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     // a persistent workgroup walks all N / 128 chunks of its tiles one after the other: below ~half a GPU of tiles (small
     // batches; B = 1: 13 tiles at 40 x 40) the generic kernel's tiles_m x N / 128 independent workgroups are faster
     if (pw_ok && (p.y || p.y2) && ((p.Cout >> 7) & 1) == 0 && p.Cout <= 1024 && (M >= 128 * 128 || p.force_tile == 6)) return p.Cin == 64 ? launch_pw_stream_nk<1>(p, s) : (p.Cin == 128 ? launch_pw_stream_nk<2>(p, s) : launch_pw_stream_nk<4>(p, s));
+    // wide pointwise GEMMs that pw_stream does not take (conv3 + fused shortcut of the down-sampling units, stage-4 conv3, and
+    // N >= 512 conv1s, where the 256 x 256 tile measured faster than pw_gemm's 256 x 128: 32.8 vs 39.3 us for 1024 -> 512 at
+    // 40 x 40 x 16): persistent 256 x 256 tiles (force_tile 12: whatever the size; 1 / 2 / 7 opt out)
+    const bool pww_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.in_scale && !p.yf && (p.y || p.y2) &&
+                        (!p.res || (!p.res_up2 && !p.res_post)) && p.Cin2 % 64 == 0 && p.Cin + p.Cin2 >= 384 && p.Cout % 256 == 0 &&
+                        p.Cout >= 512 && p.Cout <= 2048 && p.y_split >= p.Cout && p.n_valid >= p.Cout && M % 8 == 0 &&
+                        (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 12);
+    if (pww_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 256) >= 150)) return launch_pw_wide(p, s);
     // long-K pointwise layers without a residual (conv1 of the units): persistent activation-streaming kernel
     // (force_tile 15: whatever the size; 1 / 2 / 7 opt out)
     const bool pwg_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.res && !p.y2 && !p.yf &&
                         p.y && p.Cin % 128 == 0 && p.Cin >= 256 && p.Cin <= 2048 && p.Cout % 128 == 0 && p.Cout <= 1024 && p.y_split >= p.Cout &&
                         p.n_valid >= p.Cout && M % 8 == 0 && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 15);
     if (pwg_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 128) >= 150)) return launch_pw_gemm(p, s);
-    // wide pointwise GEMMs left over by the two streaming kernels (conv3 + fused shortcut of the down-sampling units, stage-4
-    // conv3): persistent 256 x 256 tiles (force_tile 12: whatever the size; 1 / 2 / 7 opt out)
-    const bool pww_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.in_scale && !p.yf && (p.y || p.y2) &&
-                        (!p.res || (!p.res_up2 && !p.res_post)) && p.Cin2 % 64 == 0 && p.Cin + p.Cin2 >= 384 && p.Cout % 256 == 0 &&
-                        p.Cout >= 512 && p.Cout <= 2048 && p.y_split >= p.Cout && p.n_valid >= p.Cout && M % 8 == 0 &&
-                        (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 12);
-    if (pww_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 256) >= 150)) return launch_pw_wide(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&
