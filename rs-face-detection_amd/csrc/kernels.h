@@ -152,6 +152,7 @@ struct B2BParams {
     const float *bias1;
     bf16_t *t1;                // [M][64]
     int B, H, W, Cin, Cin2;
+    int force_tile;            // as ConvParams::force_tile (6: persistent form forced, 7 / 1 / 2: never)
 };
 int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s);
 // conv0: 7x7 stride 2 pad 3 on the NHWC4 input, fused bias + ReLU -> [B][H/2][W/2][64]

@@ -1830,6 +1830,180 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
     }
 }
 
+// Persistent form of the back-to-back kernel for K1 = 64 (no fused shortcut: units 2.. of stage 1).  The kernel above
+// re-stages W3 (32 KiB) and W1 (32 KiB) for every 128-pixel tile -- as many bytes as the tile's activation and residual --
+// and runs its five phases strictly one after the other: 11 us per tile where the tile's HBM traffic (160 KiB) needs 6.
+// Here a workgroup owns the CU, keeps both filter banks in LDS for its lifetime and walks tiles: the NEXT tile's activation
+// tile is requested right after phase 1 has read the current one (it lands under epilogue 1 + phase 2), the next tile's
+// residual after epilogue 1 has consumed the current one.  Drain-only waits (DESIGN.md section 5 rule 1): the one at the top
+// of a tile covers DMAs and stores issued at least a phase earlier.  Same arithmetic in the same order: bit-identical.
+__global__ void __launch_bounds__(512) conv_b2b_s1_persistent_kernel(const B2BParams p, int ntiles)
+{
+    constexpr int BM = 128, N1 = 256, N2 = 64, K1 = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [128][64]
+    bf16_t *W3s = Xs + BM * 64;                      // [256][64]   resident
+    bf16_t *A2 = W3s + N1 * 64;                      // [4][128][64] k-tiles of the activated tile
+    bf16_t *W1s = A2 + 4 * BM * 64;                  // [4][64][64] resident
+    // bias3 | scale | shift [256 each] | bias1 [64]: in LDS, so that the epilogues issue no global loads -- a load issued behind the
+    // next tile's activation DMA could only be waited for together with it
+    float *Tab = reinterpret_cast<float *>(W1s + 4 * N2 * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1; // phase 1: 2 (m) x 4 (n) waves, 64 x 64 each
+    const int M = p.B * p.H * p.W;
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * K1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w3), 0, (uint32_t)((size_t)N1 * K1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w1), 0, (uint32_t)((size_t)N2 * N1 * 2), 0x00020000);
+    auto perm64 = [](int rho) { const int i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3; return (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_; };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    for (int c = tid; c < N1; c += 512) {
+        Tab[c] = p.bias3[c];
+        Tab[N1 + c] = p.scale[c];
+        Tab[2 * N1 + c] = p.shift[c];
+        if (c < N2) Tab[3 * N1 + c] = p.bias1[c];
+    }
+
+    auto stage_x = [&](int t) { // activation tile of tile t: 2 pieces / wave
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = wave + 8 * q, m = t * BM + piece * 8 + lr;
+            blds16(rx, m < M ? (uint32_t)(((size_t)m * K1 + chunk * 8) * 2) : kOob, 0, Xs + piece * 512);
+        }
+    };
+    uint4 resv[4][2]; // residual of this wave's 64 x 64 output slice: [j][h] = pixel j*16+frow, channels h*32+fq*8..+7
+    auto load_res = [&](int t) {
+        if (!p.res) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = t * BM + wm * 64 + j * 16 + frow;
+            const size_t mr = (size_t)(m < M ? m : 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) resv[j][h] = *reinterpret_cast<const uint4 *>(p.res + mr * N1 + wn * 64 + h * 32 + fq * 8);
+        }
+    };
+    // once: W3 (4 pieces / wave), W1 (4 pieces / wave: [4 k-tiles][64 rows][64], piece = kt2*8 + row/8)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave + 8 * q, rho = piece * 8 + lr; // 0..255
+        const int chn = (rho & ~63) + perm64(rho & 63);
+        blds16(rw3, (uint32_t)(((size_t)chn * K1 + chunk * 8) * 2), 0, W3s + piece * 512);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave + 8 * q, kt2 = piece >> 3, rho = (piece & 7) * 8 + lr;
+        blds16(rw1, (uint32_t)(((size_t)perm64(rho) * N1 + chunk * 8) * 2), (uint32_t)(kt2 << 7), W1s + piece * 512);
+    }
+    stage_x(tile);
+    load_res(tile);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BM, next = tile + gridDim.x;
+        // this tile's activation (requested a phase 2 + ... ago; the first time: + the filter banks) is in LDS in every wave
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- phase 1: acc1[64 n x 64 m per wave], one K step ----
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const bf16_t *xs = Xs + (wm * 64) * 64, *ws = W3s + (wn * 64) * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[4];
+                const int ch = kk * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int r = i * 16 + frow; af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3)); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int r = j * 16 + frow; bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3)); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // every wave has read Xs (and, from the previous tile's phase 2, A2): the next activation tile may land
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (next < ntiles) stage_x(next);
+
+        // ---- epilogue 1: raw -> HBM, relu(affine(raw)) -> LDS operand tile (k-tile = wn, chunk = h*4 + fq) ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = wn * 64 + h * 32 + fq * 8;
+            float bias[8], s2[8], t2[8];
+            lds_table_read8(Tab + n, bias);
+            lds_table_read8(Tab + N1 + n, s2);
+            lds_table_read8(Tab + 2 * N1 + n, t2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + frow, m = m0 + row;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = acc[2 * h][j][k] + bias[k]; v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k]; }
+                if (p.res) {
+                    const uint4 rv = resv[j][h];
+                    v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                    v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                    v[4] += bf16_bits_to_f32(rv.z & 0xffffu); v[5] += bf16_bits_to_f32(rv.z >> 16);
+                    v[6] += bf16_bits_to_f32(rv.w & 0xffffu); v[7] += bf16_bits_to_f32(rv.w >> 16);
+                }
+                const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+                if (m < M) *reinterpret_cast<uint4 *>(p.raw + (size_t)m * N1 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                // the consumer conv1 sees relu(affine(bf16(raw))): same rounding points as the unfused pair
+                float a[8];
+                const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[2 * k] = fmaxf(bf16_bits_to_f32(rb[k] & 0xffffu) * s2[2 * k] + t2[2 * k], 0.f);
+                    a[2 * k + 1] = fmaxf(bf16_bits_to_f32(rb[k] >> 16) * s2[2 * k + 1] + t2[2 * k + 1], 0.f);
+                }
+                const uint2 alo = pack_bf16x4(a[0], a[1], a[2], a[3]), ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                const int c = h * 4 + fq;
+                *reinterpret_cast<uint4 *>(A2 + wn * BM * 64 + row * 64 + ((c ^ (row & 7)) << 3)) = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+            }
+        }
+        if (next < ntiles) load_res(next); // consumed above; lands under phase 2 and the next tile's phase 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the operand tile is complete (LDS only: no DMA wait here)
+
+        // ---- phase 2: t1[16 pixels x 64 channels per wave] = A2[128 x 256] . W1^T ----
+        f32x4 acc2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt2 = 0; kt2 < 4; ++kt2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ch = kk * 4 + fq;
+                const int r = wave * 16 + frow;
+                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(A2 + kt2 * BM * 64 + r * 64 + ((ch ^ (r & 7)) << 3));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = i * 16 + frow;
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(W1s + kt2 * N2 * 64 + ra * 64 + ((ch ^ (ra & 7)) << 3));
+                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        const int m = m0 + wave * 16 + frow;
+        {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = h * 32 + fq * 8;
+                float b1v[8];
+                lds_table_read8(Tab + 3 * N1 + n, b1v);
+                const uint2 lo = pack_bf16x4(fmaxf(acc2[2 * h][0] + b1v[0], 0.f), fmaxf(acc2[2 * h][1] + b1v[1], 0.f), fmaxf(acc2[2 * h][2] + b1v[2], 0.f), fmaxf(acc2[2 * h][3] + b1v[3], 0.f));
+                const uint2 hi = pack_bf16x4(fmaxf(acc2[2 * h + 1][0] + b1v[4], 0.f), fmaxf(acc2[2 * h + 1][1] + b1v[5], 0.f), fmaxf(acc2[2 * h + 1][2] + b1v[6], 0.f), fmaxf(acc2[2 * h + 1][3] + b1v[7], 0.f));
+                if (m < M) *reinterpret_cast<uint4 *>(p.t1 + (size_t)m * N2 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+}
+
 int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
 {
     if (p.Cin != 64 || (p.Cin2 != 0 && p.Cin2 != 64)) {
@@ -1838,6 +2012,17 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     }
     const int M = p.B * p.H * p.W;
     const size_t lds = (size_t)(128 * 64 + 256 * 64 + 4 * 128 * 64 + 4 * 64 * 64) * sizeof(bf16_t); // 144 KiB
+    const int ntiles = ceil_div(M, 128);
+    // K1 = 64 and at least two tiles per CU: the persistent form (force_tile 7 opts out, 6 forces it whatever the size)
+    if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
+        const int per = ceil_div(ntiles, 256);
+        const int grid = ceil_div(ntiles, per);
+        static DynLdsOnce once_p;
+        RFD_TRY(once_p.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_kernel), 160 * 1024));
+        hipLaunchKernelGGL(conv_b2b_s1_persistent_kernel, dim3(grid), dim3(512), 160 * 1024, s, p, ntiles); // the whole CU
+        RFD_HIP(hipGetLastError());
+        return RFD_OK;
+    }
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv_b2b_s1_kernel), (int)lds));
     hipLaunchKernelGGL(conv_b2b_s1_kernel, dim3(ceil_div(M, 128)), dim3(512), lds, s, p);

@@ -701,6 +701,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             bp.bias1 = d_b + Lb.b_off;
             bp.t1 = (bf16_t *)tensor_ptr(o.out_b, batch_off);
             bp.B = B; bp.H = tin.H; bp.W = tin.W; bp.Cin = L.cin_d;
+            bp.force_tile = force_tile;
             RFD_TRY(launch_conv_b2b_s1(bp, s));
         } else if (o.kind == OP_POOL) {
             RFD_TRY(launch_maxpool3x3s2((const bf16_t *)tensor_ptr(o.in, batch_off), (bf16_t *)tensor_ptr(o.out, batch_off),

@@ -19,6 +19,9 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
     wide = set()
     for i, o in enumerate(g.ops):
         L = g.layers[o.layer]
+        if o.kind == 6 and o.layer2 < 0:   # stage-1 back-to-back kernel without a fused shortcut: persistent form (tile 6)
+            ops.append(i)
+            continue
         if o.kind != 2:
             continue
         pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin
@@ -45,7 +48,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
             if t == o.in_:
                 x = np.maximum(x, 0)
             det.debug_write(t, (x.view(np.uint32) >> 16).astype(np.uint16))
-        outs = [t for t in (o.out, o.out2) if t >= 0]
+        outs = [t for t in (o.out, o.out2, o.out_b) if t >= 0]
         res = {}
         # 7: generic kernels only; 6: persistent kernels forced whatever the problem size (the first that accepts the layer);
         # 12: pw_wide_kernel forced (layers that pw_stream / pw_gemm would take first)
