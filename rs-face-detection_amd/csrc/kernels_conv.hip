@@ -593,6 +593,14 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
     wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
 }
 
+// CUs a persistent kernel spreads over when another chain of the same pass runs beside it (RFD_PERSIST_CUS: A/B knob;
+// default: all of them)
+static int persistent_cus(int co_running)
+{
+    static const int env = [] { const char *e = getenv("RFD_PERSIST_CUS"); return e ? atoi(e) : 0; }();
+    return co_running && env > 0 ? env : 256;
+}
+
 template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
@@ -604,6 +612,7 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
         if (!cu_count[dev]) { hipDeviceProp_t pr; RFD_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         ncu = cu_count[dev];
     }
+    if (persistent_cus(p.co_running) < ncu) ncu = persistent_cus(p.co_running);
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
@@ -927,7 +936,7 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
 {
     const int tiles_x = ceil_div(p.W, kC64T), tiles_y = ceil_div(p.H, kC64T);
     const int ntiles = p.B * tiles_x * tiles_y;
-    const int ncu = 256;
+    const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(ntiles, ncu);
     const int grid = ceil_div(ntiles, per); // even share per persistent workgroup: no tail
     // needs 154 KiB; asks for the whole CU's LDS so that no other kernel's workgroup can ever share the CU (see launch_pw_stream)
@@ -1188,7 +1197,7 @@ template <int TC, int TR, int TN> static int launch_conv3x3_halo(const ConvParam
 {
     const int tiles_x = ceil_div(p.W, TC), tiles_y = ceil_div(p.H, TR);
     const int n_items = p.B * tiles_x * tiles_y * (p.Cout / (32 * TN));
-    const int ncu = 256;
+    const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
     const size_t lds = 160 * 1024; // the whole CU, always: see launch_pw_stream
@@ -1410,7 +1419,7 @@ static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.H * p.W;
     const int tiles_m = ceil_div(M, 256), n_items = tiles_m * (p.Cout / 128);
-    const int ncu = 256;
+    const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
     const size_t lds = 160 * 1024; // 3 x 32 + 2 x 16 KiB + bias table; the whole CU, always (see launch_pw_stream)
@@ -1639,7 +1648,7 @@ static int launch_pw_wide(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int n_items = ceil_div(M, 256) * (p.Cout / 256);
-    const int ncu = 256;
+    const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
     const size_t lds = 160 * 1024; // 4 x 32 KiB + tables; the whole CU, always (see launch_pw_stream)
@@ -2015,7 +2024,7 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     const int ntiles = ceil_div(M, 128);
     // K1 = 64 and at least two tiles per CU: the persistent form (force_tile 7 opts out, 6 forces it whatever the size)
     if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
-        const int per = ceil_div(ntiles, 256);
+        const int per = ceil_div(ntiles, persistent_cus(1));
         const int grid = ceil_div(ntiles, per);
         static DynLdsOnce once_p;
         RFD_TRY(once_p.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_kernel), 160 * 1024));
