@@ -134,3 +134,47 @@ def test_halo_kernel_equals_merged_kx_kernel_bitwise(rfd, n):
     det.debug_set_conv_tile(0)
     det.close()
     assert checked >= 12
+
+
+@pytest.mark.parametrize("size", [(768, 480), (640, 448)])
+def test_forced_persistent_kernels_on_other_input_sizes(rfd, size):
+    """Feature maps that do not divide into the persistent kernels' items: 96 x 60 / 48 x 30 (16 x 16 halo tiles with a partial
+    last tile row, at 768 x 480) and 80 x 56 / 40 x 28 (the 40-wide row tile with 4 of 6 rows in its last item, at 640 x 448),
+    pixel counts that are not multiples of 256, n = 3.  Every convolution op, persistent kernels forced (6) against the
+    generic / merged-kx kernels (7): bit-identical, NaN-poisoned outputs fully overwritten where the op writes."""
+    n = 3
+    det = rfd.RetinaFaceDetection(image_size=size, max_batch_size=n, max_det=16)
+    det.init_synthetic_weights(77)
+    g = rfd.Graph(rfd.BACKBONE_R50, size[0], size[1])
+    rng = np.random.default_rng(size[0])
+    checked = 0
+    for i, o in enumerate(g.ops):
+        if o.kind not in (2, 6):
+            continue
+        L = g.layers[o.layer]
+        for t in (o.in_, o.res, o.in2):
+            if t < 0:
+                continue
+            td = g.tensors[t]
+            x = rng.normal(0, 1, size=(n, td.height, td.width, td.channels)).astype(np.float32)
+            if t == o.in_:
+                x = np.maximum(x, 0)
+            det.debug_write(t, (x.view(np.uint32) >> 16).astype(np.uint16))
+        outs = [t for t in (o.out, o.out2, o.out_b) if t >= 0 and not g.tensors[t].is_f32]
+        res = {}
+        for tile in (7, 6):
+            det.debug_set_conv_tile(tile)
+            for t in outs:
+                if t != o.in_:
+                    td = g.tensors[t]
+                    det.debug_write(t, np.full((n, td.height, td.width, td.channels), 0x7fc0, np.uint16))
+            det.debug_run(n, i, i)
+            res[tile] = [det.debug_read(t, n, g.tensors[t]) for t in outs]
+        for t, a, b in zip(outs, res[6], res[7]):
+            if t == o.in_:
+                a, b = a[..., o.y_coff:o.y_coff + L.cout], b[..., o.y_coff:o.y_coff + L.cout]
+            assert np.array_equal(a, b), "op %d (%s) tensor %d at %s" % (i, L.name.decode(), t, size)
+            checked += 1
+    det.debug_set_conv_tile(0)
+    det.close()
+    assert checked >= 60
