@@ -595,9 +595,11 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 
 // CUs a persistent kernel spreads over when another chain of the same pass runs beside it (RFD_PERSIST_CUS: A/B knob;
 // default: all of them)
-static int persistent_cus(int co_running)
+static int persistent_cus(int co_running, bool hbm_bound = false)
 {
     static const int env = [] { const char *e = getenv("RFD_PERSIST_CUS"); return e ? atoi(e) : 0; }();
+    static const int env_hbm = [] { const char *e = getenv("RFD_PERSIST_CUS_HBM"); return e ? atoi(e) : 0; }(); // HBM-bound kernels only
+    if (co_running && hbm_bound && env_hbm > 0) return env_hbm;
     return co_running && env > 0 ? env : 256;
 }
 
@@ -612,7 +614,7 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
         if (!cu_count[dev]) { hipDeviceProp_t pr; RFD_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         ncu = cu_count[dev];
     }
-    if (persistent_cus(p.co_running) < ncu) ncu = persistent_cus(p.co_running);
+    if (persistent_cus(p.co_running, true) < ncu) ncu = persistent_cus(p.co_running, true);
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
@@ -1419,7 +1421,7 @@ static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.H * p.W;
     const int tiles_m = ceil_div(M, 256), n_items = tiles_m * (p.Cout / 128);
-    const int ncu = persistent_cus(p.co_running);
+    const int ncu = persistent_cus(p.co_running, true);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
     const size_t lds = 160 * 1024; // 3 x 32 + 2 x 16 KiB + bias table; the whole CU, always (see launch_pw_stream)
@@ -2024,7 +2026,7 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     const int ntiles = ceil_div(M, 128);
     // K1 = 64 and at least two tiles per CU: the persistent form (force_tile 7 opts out, 6 forces it whatever the size)
     if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
-        const int per = ceil_div(ntiles, persistent_cus(1));
+        const int per = ceil_div(ntiles, persistent_cus(1, true));
         const int grid = ceil_div(ntiles, per);
         static DynLdsOnce once_p;
         RFD_TRY(once_p.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_kernel), 160 * 1024));
