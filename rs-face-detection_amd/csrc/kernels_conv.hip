@@ -1331,6 +1331,25 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
             advance(wi_it, wi_k);
             advance(xi_it, xi_k);
             xis = xis == 2 ? 0 : xis + 1;
+            if (HAS_AFF) {
+                // x' = relu(x * scale[c] + shift[c]) applied ONCE per element, in place in the landed tile (the same f32 multiply,
+                // add, max and rounding as the generic kernel does on its fragments -- there each element is transformed by
+                // both channel waves that read it, and the VALU work, not HBM, set this kernel's pace).  Thread -> logical
+                // 8-channel chunk tid & 7 of rows (tid >> 3) + 64 i: one table read per step, 1 KiB contiguous per wave access.
+                const int cch = tid & 7, r0 = tid >> 3;
+                float ss[8], tt[8];
+                lds_table_read8(Sc + k * 64 + cch * 8, ss);
+                lds_table_read8(Sc + K + k * 64 + cch * 8, tt);
+                bf16_t *xt = Xs + xs * XEL + r0 * 64 + ((cch ^ (r0 & 7)) << 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8 *>(xt + i * 64 * 64);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
+                    *reinterpret_cast<bf16x8 *>(xt + i * 64 * 64) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
             const bf16_t *xb = Xs + xs * XEL, *wb = Ws + ws * WEL;
             bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
@@ -1340,23 +1359,6 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024 + (kk ? wa1 : wa0));
             }
-            if (HAS_AFF) {
-                // this lane's 8 operand elements are input channels k * 64 + kk * 32 + fq * 8 .. + 7 of one pixel (same arithmetic
-                // as the generic kernel: f32 multiply, add, max, round to bf16)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    float ss[8], tt[8];
-                    lds_table_read8(Sc + k * 64 + kk * 32 + fq * 8, ss);
-                    lds_table_read8(Sc + K + k * 64 + kk * 32 + fq * 8, tt);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16x8 v = bfr[kk][j];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
-                        bfr[kk][j] = v;
-                    }
-                }
-            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1364,16 +1366,14 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-            if (!HAS_AFF) {
-                // reads of the first half, then the second half's reads under the first half's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            // reads of the first half, then the second half's reads under the first half's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
             xs = xs == 2 ? 0 : xs + 1;
             ws ^= 1;
             ++k;
