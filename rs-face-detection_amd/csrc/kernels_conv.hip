@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
                 for (int j = 0; j < TM; ++j) {
                     bf16x8 v = bfr[j];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf(__builtin_fmaf((float)v[e], ss[e], tt[e]), 0.f); // one fused multiply-add: the same in every kernel that applies the input affine
                     bfr[j] = v;
                 }
             }
@@ -1345,7 +1345,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                 for (int i = 0; i < 4; ++i) {
                     bf16x8 v = *reinterpret_cast<const bf16x8 *>(xt + i * 64 * 64);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)v[e] * ss[e] + tt[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf(__builtin_fmaf((float)v[e], ss[e], tt[e]), 0.f); // one fused multiply-add: the same in every kernel that applies the input affine
                     *reinterpret_cast<bf16x8 *>(xt + i * 64 * 64) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
