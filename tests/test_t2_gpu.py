@@ -147,11 +147,11 @@ def test_t2_bf16_network_vs_f32_network(rfd, oracle):
     #      "score difference < 1e-2 on matched boxes" holds on average (4e-3) but not for every box: with random weights the
     #      fg logit moves by 0.03 on average (0.15 at the 99th percentile) between the two evaluations. ----
     assert n_cand_f32 > 1500 and n_keep_f32 > 300          # the operating point is populated
-    assert max(rel) < 0.03                                  # measured 0.003 .. 0.018: bf16 noise through ~60 layers, not a wiring error
-    assert m["fg_logit_abs_err_near_threshold"]["mean"] < 0.05              # measured 0.032
-    assert m["flip_rate_vs_f32_candidates"] < 0.10                          # measured 0.054
-    assert m["kept_same_anchor_frac"] > 0.85 and m["kept_matched_any_frac"] > 0.95   # measured 0.911 / 0.984
-    assert m["same_anchor"]["score_abs_diff"]["mean"] < 1e-2                # measured 4.3e-3
-    assert m["same_anchor"]["score_abs_diff"]["p99"] < 5e-2                 # measured 2.5e-2 (max 3.3e-2)
-    assert m["same_anchor"]["iou_mean"] > 0.985 and m["same_anchor"]["iou_min"] > 0.93   # measured 0.993 / 0.972
-    assert m["same_anchor"]["box_coord_abs_diff_px"]["max"] < 5.0           # measured 2.2 px on 640 x 640 frames
+    assert max(rel) < 0.03                                  # measured 0.003 .. 0.019: bf16 noise through ~60 layers, not a wiring error
+    assert m["fg_logit_abs_err_near_threshold"]["mean"] < 0.05              # measured 0.033
+    assert m["flip_rate_vs_f32_candidates"] < 0.10                          # measured 0.058 (0.054 mid-round)
+    assert m["kept_same_anchor_frac"] > 0.85 and m["kept_matched_any_frac"] > 0.95   # measured 0.933 / 0.984
+    assert m["same_anchor"]["score_abs_diff"]["mean"] < 1e-2                # measured 4.6e-3
+    assert m["same_anchor"]["score_abs_diff"]["p99"] < 5e-2                 # measured 3.0e-2 (max 3.9e-2)
+    assert m["same_anchor"]["iou_mean"] > 0.985 and m["same_anchor"]["iou_min"] > 0.93   # measured 0.993 / 0.969
+    assert m["same_anchor"]["box_coord_abs_diff_px"]["max"] < 5.0           # measured 2.8 px on 640 x 640 frames
