@@ -970,7 +970,7 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
 // chunk boundary and the two halo buffers are bound to chunk parity).
 // ------------------------------------------------------------------------------------------------
 #ifndef RFD_HALO_EXP
-#define RFD_HALO_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage): 1 no weight DMA, 2 no halo DMA, 3 neither, 4 neither + no barrier
+#define RFD_HALO_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage): 1 no weight DMA, 2 no halo DMA, 3 neither, 4 neither + no barrier, 5 weight DMAs issued but never waited for
 #endif
 template <int TC, int TR, int TN>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int n_items)
@@ -1079,17 +1079,21 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, i
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             // weights of this step were issued a step ago; a halo tile 4+ steps ago (the bias table, the first time, by plain stores)
+#if RFD_HALO_EXP == 5 // timing only: the weight waves never wait for their DMAs (is the step waiting for the weights to land?)
+            if (wn != 0 && (s == 0 || (U == 2 && s == 4))) wait_vmcnt<0>();
+#else
             if (wn == 0 || s == 0 || (U == 2 && s == 4)) wait_vmcnt<0>();
+#endif
 #if RFD_HALO_EXP != 4
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 2
+#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 2 || RFD_HALO_EXP == 5
             if (wn == 0) {
                 if (s < 8) issue_w(wslot ^ 1, item, c0, s + 1);
                 else if (has_next) issue_w(wslot ^ 1, nitem, nc0, 0);
             }
 #endif
-#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 1
+#if RFD_HALO_EXP == 0 || RFD_HALO_EXP == 1 || RFD_HALO_EXP == 5
             if (wn == 1 && U == 1) {
                 if (s == 0 && has_next) issue_halo(nitem, nc0, hbuf ^ 1);
             } else if (wn == 1) {
