@@ -1322,15 +1322,47 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
     if (wn == 1 && xgrp == 1 && xi_it < n_items) issue_x(1, xi_it, xi_k);
     advance(xi_it, xi_k);
     int xis = 2; // slot of the next activation step to request
+    // optional residual (FPN laterals: the coarser level, nearest-2x upsampled, added after the ReLU): requested into registers
+    // with untracked buffer loads in the item's FIRST step and used in its epilogue -- every wave drains its counter at least
+    // once in between (KC >= 4), the same arrangement as pw_stream's
+    const int HoWo = p.Ho * p.Wo;
+    const u32x4 rres = make_srd(p.res ? p.res : p.x, p.res ? (uint32_t)((size_t)(p.res_up2 ? p.B * (p.Ho >> 1) * (p.Wo >> 1) : M) * p.Cout * 2) : 0u);
+    u32x4 resv[2][4];
     while (true) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) { // KC is even: step parity == K-step parity, the pair roles are static
-            if (wn == 0 || xgrp == par) wait_vmcnt<0>();
+            if (wn == 0 || xgrp == par) {
+                // (the residual registers were written by untracked loads in the previous step: tie them to this drain, so that
+                //  the compiler cannot move or copy them before the data is there)
+                if (par == 1 && k == 1 && p.res) {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(resv[0][0]), "+v"(resv[0][1]), "+v"(resv[0][2]), "+v"(resv[0][3])::"memory");
+                    asm volatile("" : "+v"(resv[1][0]), "+v"(resv[1][1]), "+v"(resv[1][2]), "+v"(resv[1][3])::"memory");
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (wn == 0) {
                 if (wi_it < n_items) issue_w(ws ^ 1, wi_it, wi_k);
             } else if (xgrp == par) {
                 if (xi_it < n_items) issue_x(xis, xi_it, xi_k);
+            }
+            if (par == 0 && k == 0 && p.res) {
+                const int m0r = (item / tiles_n) * BM, n0r = (item % tiles_n) * NWG;
+                int frow_ = frow;
+                asm volatile("" : "+v"(frow_));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0r + wm * 64 + j * 16 + frow_;
+                    size_t mr = (size_t)(m < M ? m : 0);
+                    if (p.res_up2 && m < M) {
+                        const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        mr = ((size_t)b * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+                    }
+#pragma unroll
+                    for (int ip = 0; ip < 2; ++ip)
+                        asm_buffer_load_b128(resv[ip][j], (uint32_t)((mr * p.Cout + n0r + wn * 64 + ip * 32 + fq * 8) * 2), rres);
+                }
             }
             advance(wi_it, wi_k);
             advance(xi_it, xi_k);
@@ -1378,6 +1410,12 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            // waves 4-5 do not drain at the top of this (odd) step: theirs comes here, inside the same loop iteration as the loads
+            // (everything they have in flight -- the activation step requested a step ago -- is due at the next step's top anyway)
+            if (par == 1 && k == 1 && p.res && wn == 1 && xgrp == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(resv[0][0]), "+v"(resv[0][1]), "+v"(resv[0][2]), "+v"(resv[0][3])::"memory");
+                asm volatile("" : "+v"(resv[1][0]), "+v"(resv[1][1]), "+v"(resv[1][2]), "+v"(resv[1][3])::"memory");
+            }
             xs = xs == 2 ? 0 : xs + 1;
             ws ^= 1;
             ++k;
@@ -1399,9 +1437,25 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                         o[e] = acc[2 * ip][j][e] + bias[e];
                         o[4 + e] = acc[2 * ip + 1][j][e] + bias[4 + e];
                     }
+                    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (p.res) {
+                        const u32x4 rv = resv[ip][j];
+                        r[0] = bf16_bits_to_f32(rv[0] & 0xffffu); r[1] = bf16_bits_to_f32(rv[0] >> 16);
+                        r[2] = bf16_bits_to_f32(rv[1] & 0xffffu); r[3] = bf16_bits_to_f32(rv[1] >> 16);
+                        r[4] = bf16_bits_to_f32(rv[2] & 0xffffu); r[5] = bf16_bits_to_f32(rv[2] >> 16);
+                        r[6] = bf16_bits_to_f32(rv[3] & 0xffffu); r[7] = bf16_bits_to_f32(rv[3] >> 16);
+                        if (!p.res_post) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += r[e];
+                        }
+                    }
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+                    }
+                    if (p.res && p.res_post) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += r[e];
                     }
                     const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
                     const uint32_t yoff = (uint32_t)(((size_t)m * p.ldy + p.y_coff + ch0) * 2);
@@ -2114,10 +2168,12 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     if (pww_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 256) >= 150)) return launch_pw_wide(p, s);
     // long-K pointwise layers without a residual (conv1 of the units): persistent activation-streaming kernel
     // (force_tile 15: whatever the size; 1 / 2 / 7 opt out)
-    const bool pwg_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.res && !p.y2 && !p.yf &&
+    const bool pwg_ok = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin2 == 0 && !p.y2 && !p.yf && p.Ho == p.H && p.Wo == p.W &&
                         p.y && p.Cin % 128 == 0 && p.Cin >= 256 && p.Cin <= 2048 && p.Cout % 128 == 0 && p.Cout <= 1024 && p.y_split >= p.Cout &&
                         p.n_valid >= p.Cout && M % 8 == 0 && (p.force_tile == 0 || p.force_tile == 6 || p.force_tile == 15);
-    if (pwg_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 128) >= 150)) return launch_pw_gemm(p, s);
+    // (with a residual -- the FPN laterals -- only from 400 items: 52 vs 57 us for 512 -> 256 at 80 x 80 x 16, but 27 vs 25 us for the
+    //  200 items of 1024 -> 256 at 40 x 40)
+    if (pwg_ok && (p.force_tile != 0 || ceil_div(M, 256) * (p.Cout / 128) >= (p.res ? 400 : 150))) return launch_pw_gemm(p, s);
     // 64 -> 64 3x3: filter bank resident in LDS, halo tile staged once for all nine taps (force_tile 1 / 2 / 7 opt out)
     const bool c64_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.Cin2 == 0 && !p.in_scale &&
                         !p.res && !p.y2 && !p.yf && p.y && p.Ho == p.H && p.Wo == p.W && p.y_split >= 64 && p.n_valid >= 64 &&

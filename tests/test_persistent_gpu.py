@@ -27,7 +27,8 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
         pw = L.kh == 1 and o.res >= 0 and o.layer2 < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin
         c64 = L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0
         # pw_gemm_kernel: long-K pointwise layers without a residual (conv1 of the units)
-        pwg = L.kh == 1 and L.stride == 1 and o.res < 0 and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 \
+        # (with or without a residual: the FPN laterals add the coarser level, nearest-2x upsampled, after the ReLU)
+        pwg = L.kh == 1 and L.stride == 1 and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 \
             and o.layer_b < 0 and L.cin % 128 == 0 and L.cin >= 256 and L.cout % 128 == 0 and L.cout <= 1024
         # pw_wide_kernel: wide pointwise GEMMs (conv3 + fused stride-2 shortcut of the down-sampling units, stage-4 conv3)
         kk = L.cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0)

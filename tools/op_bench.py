@@ -42,7 +42,7 @@ elif a.ops == "halo":  # the layers conv3x3_halo_kernel accepts
            and g.layers[o.layer].cin % 128 == 0 and g.layers[o.layer].cout % 128 == 0 and g.layers[o.layer].cout <= 512
            and o.res < 0 and o.layer_n2 < 0 and g.tensors[o.in_].width in (80, 40)]
 elif a.ops == "pwg":  # the layers pw_gemm_kernel accepts
-    ops = [k for k, o in enumerate(g.ops) if o.kind == 2 and g.layers[o.layer].kh == 1 and g.layers[o.layer].stride == 1 and o.res < 0
+    ops = [k for k, o in enumerate(g.ops) if o.kind == 2 and g.layers[o.layer].kh == 1 and g.layers[o.layer].stride == 1
            and o.layer2 < 0 and o.out2 < 0 and o.outf < 0 and g.layers[o.layer].cin % 128 == 0
            and g.layers[o.layer].cin >= 256 and g.layers[o.layer].cout % 128 == 0 and g.layers[o.layer].cout <= 1024]
 elif a.ops == "pww":  # the layers pw_wide_kernel accepts
