@@ -34,8 +34,8 @@ def conv_class(o, L, n_out):
     if L.kh == 1 and L.stride == 1 and o.res >= 0 and o.layer2 < 0 and o.in_affine < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin \
             and L.cout <= 1024 and not o.res_up2 and not o.res_post and plain_out and M >= 128 * 128:
         return "rfd::pw_stream_kernel"
-    if L.kh == 1 and L.stride == 1 and o.res < 0 and o.layer2 < 0 and o.out2 < 0 and plain_out and L.cin % 128 == 0 and 256 <= L.cin <= 2048 \
-            and L.cout % 128 == 0 and L.cout <= 1024 and -(-M // 256) * (L.cout // 128) >= 150:
+    if L.kh == 1 and L.stride == 1 and o.layer2 < 0 and o.out2 < 0 and plain_out and L.cin % 128 == 0 and 256 <= L.cin <= 2048 \
+            and L.cout % 128 == 0 and L.cout <= 1024 and -(-M // 256) * (L.cout // 128) >= (400 if o.res >= 0 else 150):
         return "rfd::pw_gemm_kernel"
     kk = L.cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0)
     if L.kh == 1 and L.stride == 1 and o.in_affine < 0 and plain_out and kk >= 384 and L.cout % 256 == 0 and 512 <= L.cout <= 2048 \
