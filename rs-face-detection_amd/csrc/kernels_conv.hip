@@ -2073,6 +2073,149 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_kernel(const B2BPa
     }
 }
 
+// Persistent form for K1 = 128 (unit 1 of stage 1: conv3 + the fused 1x1 shortcut, no residual).  That unit moves half the bytes
+// of the others and still took as long in the one-tile-per-workgroup kernel (1.4 TB/s): per 128-pixel tile it re-staged 96 KiB
+// of filter banks and ran its phases one after the other.  Both banks (64 + 32 KiB) only fit LDS next to the operand tile if
+// the tile is 64 pixels: Xs 16 + W3 64 + A2 32 + W1 32 = 144 KiB.  Phase 1: 8 waves x (64 pixels x 32 channels); phase 2:
+// 4 x 2 waves x (16 pixels x 32 channels).  Same K order and arithmetic as conv_b2b_s1_kernel: bit-identical.
+__global__ void __launch_bounds__(512) conv_b2b_s1_persistent_k128_kernel(const B2BParams p, int ntiles)
+{
+    constexpr int BM = 64, N1 = 256, N2 = 64, K1 = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [2 k-tiles][64][64]
+    bf16_t *W3s = Xs + 2 * BM * 64;                  // [2 k-tiles][256][64] resident
+    bf16_t *A2 = W3s + 2 * N1 * 64;                  // [4 k-tiles][64][64]  the activated tile
+    bf16_t *W1s = A2 + 4 * BM * 64;                  // [4 k-tiles][64][64]  resident
+    float *Tab = reinterpret_cast<float *>(W1s + 4 * N2 * 64); // bias3 + bias3b | scale | shift [256 each] | bias1 [64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.B * p.H * p.W;
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * 64 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x2), 0, (uint32_t)((size_t)M * 64 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w3), 0, (uint32_t)((size_t)N1 * K1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w1), 0, (uint32_t)((size_t)N2 * N1 * 2), 0x00020000);
+    auto perm64 = [](int rho) { const int i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3; return (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_; };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    for (int c = tid; c < N1; c += 512) {
+        Tab[c] = p.bias3b ? p.bias3[c] + p.bias3b[c] : p.bias3[c];
+        Tab[N1 + c] = p.scale[c];
+        Tab[2 * N1 + c] = p.shift[c];
+        if (c < N2) Tab[3 * N1 + c] = p.bias1[c];
+    }
+    auto stage_x = [&](int t) { // 16 pieces: k-tile 0 from x, k-tile 1 from the shortcut's input x2; 2 per wave
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = wave + 8 * q, kt = piece >> 3, m = t * BM + (piece & 7) * 8 + lr;
+            const uint32_t off = m < M ? (uint32_t)(((size_t)m * 64 + chunk * 8) * 2) : kOob;
+            if (kt == 0) blds16(rx, off, 0, Xs + piece * 512);
+            else blds16(rx2, off, 0, Xs + piece * 512);
+        }
+    };
+    // once: W3 (2 k-tiles x 32 pieces: 8 / wave), W1 (32 pieces: 4 / wave)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int piece = wave + 8 * q, kt = piece >> 5, rho = (piece & 31) * 8 + lr; // row 0..255
+        const int chn = (rho & ~63) + perm64(rho & 63);
+        blds16(rw3, (uint32_t)(((size_t)chn * K1 + chunk * 8) * 2), (uint32_t)(kt << 7), W3s + piece * 512);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave + 8 * q, kt2 = piece >> 3, rho = (piece & 7) * 8 + lr;
+        blds16(rw1, (uint32_t)(((size_t)perm64(rho) * N1 + chunk * 8) * 2), (uint32_t)(kt2 << 7), W1s + piece * 512);
+    }
+    stage_x(tile);
+
+    const int sw0 = (fq ^ (frow & 7)) << 3, sw1 = sw0 ^ 32; // chunk position of the two 32-wide K halves for rows = frow mod 8
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BM, next = tile + gridDim.x;
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- phase 1: acc[2 x 16 channels][4 x 16 pixels] per wave over K1 = 2 k-tiles x 2 halves ----
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[2], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8 *>(W3s + kt * N1 * 64 + (wave * 32 + i * 16 + frow) * 64 + (kk ? sw1 : sw0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8 *>(Xs + kt * BM * 64 + (j * 16 + frow) * 64 + (kk ? sw1 : sw0));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        // every wave has read Xs (and, from the previous tile's phase 2, A2): the next activation tile may land
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (next < ntiles) stage_x(next);
+
+        // ---- epilogue 1: raw -> HBM, relu(affine(bf16(raw))) -> the LDS operand tile ----
+        {
+            const int n = wave * 32 + fq * 8; // this lane's 8 consecutive channels
+            float bias[8], s2[8], t2[8];
+            lds_table_read8(Tab + n, bias);
+            lds_table_read8(Tab + N1 + n, s2);
+            lds_table_read8(Tab + 2 * N1 + n, t2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 16 + frow, m = m0 + row;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = acc[0][j][k] + bias[k]; v[4 + k] = acc[1][j][k] + bias[4 + k]; }
+                const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+                if (m < M) *reinterpret_cast<uint4 *>(p.raw + (size_t)m * N1 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                float a[8];
+                const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[2 * k] = fmaxf(bf16_bits_to_f32(rb[k] & 0xffffu) * s2[2 * k] + t2[2 * k], 0.f);
+                    a[2 * k + 1] = fmaxf(bf16_bits_to_f32(rb[k] >> 16) * s2[2 * k + 1] + t2[2 * k + 1], 0.f);
+                }
+                const uint2 alo = pack_bf16x4(a[0], a[1], a[2], a[3]), ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                const int c = (wave & 1) * 4 + fq; // 8-channel chunk inside k-tile wave >> 1
+                *reinterpret_cast<uint4 *>(A2 + (wave >> 1) * BM * 64 + row * 64 + ((c ^ (row & 7)) << 3)) = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the operand tile is complete (LDS only)
+
+        // ---- phase 2: t1[16 pixels x 32 channels per wave] = A2[64 x 256] . W1^T ----
+        f32x4 acc2[2];
+        acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pr = (wave & 3) * 16 + frow, wh = wave >> 2;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 4; ++kt2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(A2 + kt2 * BM * 64 + pr * 64 + (kk ? sw1 : sw0));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(W1s + kt2 * N2 * 64 + (wh * 32 + i * 16 + frow) * 64 + (kk ? sw1 : sw0));
+                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        {
+            const int m = m0 + pr, n = wh * 32 + fq * 8;
+            float b1v[8];
+            lds_table_read8(Tab + 3 * N1 + n, b1v);
+            const uint2 lo = pack_bf16x4(fmaxf(acc2[0][0] + b1v[0], 0.f), fmaxf(acc2[0][1] + b1v[1], 0.f), fmaxf(acc2[0][2] + b1v[2], 0.f), fmaxf(acc2[0][3] + b1v[3], 0.f));
+            const uint2 hi = pack_bf16x4(fmaxf(acc2[1][0] + b1v[4], 0.f), fmaxf(acc2[1][1] + b1v[5], 0.f), fmaxf(acc2[1][2] + b1v[6], 0.f), fmaxf(acc2[1][3] + b1v[7], 0.f));
+            if (m < M) *reinterpret_cast<uint4 *>(p.t1 + (size_t)m * N2 + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+
 int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
 {
     if (p.Cin != 64 || (p.Cin2 != 0 && p.Cin2 != 64)) {
@@ -2089,6 +2232,15 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
         static DynLdsOnce once_p;
         RFD_TRY(once_p.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_kernel), 160 * 1024));
         hipLaunchKernelGGL(conv_b2b_s1_persistent_kernel, dim3(grid), dim3(512), 160 * 1024, s, p, ntiles); // the whole CU
+        RFD_HIP(hipGetLastError());
+        return RFD_OK;
+    }
+    // K1 = 128 (fused shortcut, no residual): persistent 64-pixel tiles, both filter banks resident
+    if (p.Cin2 == 64 && !p.res && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (M >= 64 * 1024 || p.force_tile == 6)) {
+        const int nt = ceil_div(M, 64), per = ceil_div(nt, persistent_cus(1, true));
+        static DynLdsOnce once_k;
+        RFD_TRY(once_k.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_k128_kernel), 160 * 1024));
+        hipLaunchKernelGGL(conv_b2b_s1_persistent_k128_kernel, dim3(ceil_div(nt, per)), dim3(512), 160 * 1024, s, p, nt);
         RFD_HIP(hipGetLastError());
         return RFD_OK;
     }

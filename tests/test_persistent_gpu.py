@@ -19,7 +19,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
     wide = set()
     for i, o in enumerate(g.ops):
         L = g.layers[o.layer]
-        if o.kind == 6 and o.layer2 < 0:   # stage-1 back-to-back kernel without a fused shortcut: persistent form (tile 6)
+        if o.kind == 6:   # stage-1 back-to-back kernel, with and without the fused shortcut: persistent forms (tile 6)
             ops.append(i)
             continue
         if o.kind != 2:
