@@ -1243,17 +1243,24 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
 // epilogue's stores are simply queued behind the DMAs and retire with the next drain.  Same K order and MFMA sequence as
 // the generic kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_AFF> // HAS_AFF: x' = relu(x * in_scale[c] + in_shift[c]) on the operand fragments (the producer unit's BN + ReLU)
+// HAS_AFF: x' = relu(x * in_scale[c] + in_shift[c]) on the landed activation tile (the producer unit's BN + ReLU).
+// WIDE: items of 128 pixels x 256 channels (waves 2 pixel x 4 channel) instead of 256 x 128 (4 x 2) -- for N = 256 layers one
+// item then covers all output channels: the activation is read and, with HAS_AFF, transformed once instead of once per
+// 128-channel item (stage-3 conv1: 38.8 us for an HBM floor of 13).  Same per-wave 64 x 64 tile, K order and arithmetic.
+template <bool HAS_AFF, bool WIDE>
 __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int tiles_m, int n_items)
 {
-    constexpr int BM = 256, NWG = 128, XEL = BM * 64, WEL = NWG * 64;
+    constexpr int BM = WIDE ? 128 : 256, NWG = WIDE ? 256 : 128, XEL = BM * 64, WEL = NWG * 64;
+    constexpr int WMW = BM / 64; // waves along the pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem); // [3][XEL]
     bf16_t *Ws = Xs + 3 * XEL;                      // [2][WEL]
     float *Tab = reinterpret_cast<float *>(Ws + 2 * WEL); // bias[Cout <= 1024] | in_scale[K <= 2048] | in_shift[K]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WMW, wn = wave / WMW;
+    const bool is_w = wave < 4;       // waves 0-3: weight stream, 4-7: activation stream
+    const int wv = wave & 3;          // index among the weight-stream waves
     const int xgrp = (wave >> 1) & 1, xsub = wave & 1; // activation-stream waves 4-7: pair (parity of the steps it serves), half
     const int lr = lane >> 3, slot = lane & 7, frow = lane & 15, fq = lane >> 4;
     const int M = p.B * p.H * p.W, K = p.Cin, KC = K >> 6;
@@ -1279,23 +1286,23 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
     auto issue_x = [&](int xslot, int it, int k) {
         const int m0 = (it / tiles_n) * BM;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < BM / 16; ++q) {
             const int mp = m0 + (xsub + 2 * q) * 8; // first pixel of the piece: wave-uniform (M is a multiple of 8)
             const uint32_t sb = (uint32_t)(((size_t)(m0 + 16 * q) * p.ldx) * 2 + (k << 7));
             blds16(rx, mp < M ? xlane + sb : kOob, 0, Xs + xslot * XEL + (xsub + 2 * q) * 512);
         }
     };
-    // ---- weight stream: LDS row rho holds output channel perm(rho); piece (wm + 4 q) = rows (wm + 4 q) * 8 + lr ----
+    // ---- weight stream: LDS row rho holds output channel perm(rho); piece (wv + 4 q) = rows (wv + 4 q) * 8 + lr ----
     uint32_t wlane;
     {
-        const int rho = wm * 8 + lr, i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3;
+        const int rho = wv * 8 + lr, i_ = rho >> 4, fq_ = (rho >> 2) & 3, r_ = rho & 3;
         const int chn = fq_ * 8 + (i_ & 1) * 4 + r_; // + 32 q
         wlane = (uint32_t)(((size_t)chn * K + ((slot ^ lr) << 3)) * 2);
     }
     auto issue_w = [&](int wslot, int it, int k) {
         const uint32_t base = (uint32_t)((size_t)(it % tiles_n) * NWG * K * 2 + (k << 7));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) blds16(rw, wlane, base + (uint32_t)(q * 64 * K), Ws + wslot * WEL + (wm + 4 * q) * 512);
+        for (int q = 0; q < NWG / 32; ++q) blds16(rw, wlane, base + (uint32_t)(q * 64 * K), Ws + wslot * WEL + (wv + 4 * q) * 512);
     };
     auto advance = [&](int &it, int &k) {
         if (++k == KC) { k = 0; it += grid; }
@@ -1315,11 +1322,11 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
     int k = 0, xs = 0, ws = 0;
     int xi_it = item, xi_k = 0;   // next activation step to request (runs two steps ahead)
     int wi_it = item, wi_k = 0;   // next weight step to request (one step ahead)
-    if (wn == 0) issue_w(0, item, 0);
+    if (is_w) issue_w(0, item, 0);
     advance(wi_it, wi_k);
-    if (wn == 1 && xgrp == 0) issue_x(0, xi_it, xi_k);
+    if (!is_w && xgrp == 0) issue_x(0, xi_it, xi_k);
     advance(xi_it, xi_k);
-    if (wn == 1 && xgrp == 1 && xi_it < n_items) issue_x(1, xi_it, xi_k);
+    if (!is_w && xgrp == 1 && xi_it < n_items) issue_x(1, xi_it, xi_k);
     advance(xi_it, xi_k);
     int xis = 2; // slot of the next activation step to request
     // optional residual (FPN laterals: the coarser level, nearest-2x upsampled, added after the ReLU): requested into registers
@@ -1331,7 +1338,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
     while (true) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) { // KC is even: step parity == K-step parity, the pair roles are static
-            if (wn == 0 || xgrp == par) {
+            if (is_w || xgrp == par) {
                 // (the residual registers were written by untracked loads in the previous step: tie them to this drain, so that
                 //  the compiler cannot move or copy them before the data is there)
                 if (par == 1 && k == 1 && p.res) {
@@ -1342,7 +1349,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (wn == 0) {
+            if (is_w) {
                 if (wi_it < n_items) issue_w(ws ^ 1, wi_it, wi_k);
             } else if (xgrp == par) {
                 if (xi_it < n_items) issue_x(xis, xi_it, xi_k);
@@ -1378,7 +1385,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                 lds_table_read8(Sc + K + k * 64 + cch * 8, tt);
                 bf16_t *xt = Xs + xs * XEL + r0 * 64 + ((cch ^ (r0 & 7)) << 3);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < BM / 64; ++i) {
                     bf16x8 v = *reinterpret_cast<const bf16x8 *>(xt + i * 64 * 64);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf(__builtin_fmaf((float)v[e], ss[e], tt[e]), 0.f); // one fused multiply-add: the same in every kernel that applies the input affine
@@ -1412,7 +1419,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
             __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
             // waves 4-5 do not drain at the top of this (odd) step: theirs comes here, inside the same loop iteration as the loads
             // (everything they have in flight -- the activation step requested a step ago -- is due at the next step's top anyway)
-            if (par == 1 && k == 1 && p.res && wn == 1 && xgrp == 0) {
+            if (par == 1 && k == 1 && p.res && !is_w && xgrp == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(resv[0][0]), "+v"(resv[0][1]), "+v"(resv[0][2]), "+v"(resv[0][3])::"memory");
                 asm volatile("" : "+v"(resv[1][0]), "+v"(resv[1][1]), "+v"(resv[1][2]), "+v"(resv[1][3])::"memory");
             }
@@ -1475,25 +1482,27 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
     wait_vmcnt<0>();
 }
 
+template <bool AFF, bool WIDE> static int launch_pw_gemm_t(const ConvParams &p, hipStream_t s, int tiles_m, int n_items, int grid)
+{
+    const size_t lds = 160 * 1024; // 3 activation + 2 weight slots + tables; the whole CU, always (see launch_pw_stream)
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<AFF, WIDE>), (int)lds));
+    hipLaunchKernelGGL((pw_gemm_kernel<AFF, WIDE>), dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
+
 static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.H * p.W;
-    const int tiles_m = ceil_div(M, 256), n_items = tiles_m * (p.Cout / 128);
+    // 128-pixel x 256-channel items where they cover all channels of an N = 256 layer and still fill the GPU (force_tile 15: never)
+    const bool wide = p.Cout == 256 && ceil_div(M, 128) >= 150 && p.force_tile != 15;
+    const int tiles_m = ceil_div(M, wide ? 128 : 256), n_items = tiles_m * (p.Cout / (wide ? 256 : 128));
     const int ncu = persistent_cus(p.co_running, true);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
-    const size_t lds = 160 * 1024; // 3 x 32 + 2 x 16 KiB + bias table; the whole CU, always (see launch_pw_stream)
-    if (p.in_scale) {
-        static DynLdsOnce once;
-        RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<true>), (int)lds));
-        hipLaunchKernelGGL(pw_gemm_kernel<true>, dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
-    } else {
-        static DynLdsOnce once;
-        RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<false>), (int)lds));
-        hipLaunchKernelGGL(pw_gemm_kernel<false>, dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
-    }
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    if (p.in_scale) return wide ? launch_pw_gemm_t<true, true>(p, s, tiles_m, n_items, grid) : launch_pw_gemm_t<true, false>(p, s, tiles_m, n_items, grid);
+    return wide ? launch_pw_gemm_t<false, true>(p, s, tiles_m, n_items, grid) : launch_pw_gemm_t<false, false>(p, s, tiles_m, n_items, grid);
 }
 
 // ------------------------------------------------------------------------------------------------
