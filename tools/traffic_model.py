@@ -77,7 +77,7 @@ for i, o in enumerate(g.ops):
     a[2] += 1
 meas = {}
 for name, v in pm["kernels"].items():
-    base = name.split("<")[0].replace("conv_b2b_s1_persistent_kernel", "conv_b2b_s1_kernel")
+    base = name.split("<")[0].replace("conv_b2b_s1_persistent_k128_kernel", "conv_b2b_s1_kernel").replace("conv_b2b_s1_persistent_kernel", "conv_b2b_s1_kernel")
     m = meas.setdefault(base, [0.0, 0.0])
     m[0] += v["fetch_bytes_per_pass"]
     m[1] += v["write_bytes_per_pass"]
