@@ -1243,6 +1243,9 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
 // epilogue's stores are simply queued behind the DMAs and retire with the next drain.  Same K order and MFMA sequence as
 // the generic kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------
+#ifndef RFD_PWG_EXP
+#define RFD_PWG_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage)
+#endif
 // HAS_AFF: x' = relu(x * in_scale[c] + in_shift[c]) on the landed activation tile (the producer unit's BN + ReLU).
 // WIDE: items of 128 pixels x 256 channels (waves 2 pixel x 4 channel) instead of 256 x 128 (4 x 2) -- for N = 256 layers one
 // item then covers all output channels: the activation is read and, with HAS_AFF, transformed once instead of once per
@@ -1345,7 +1348,12 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(resv[0][0]), "+v"(resv[0][1]), "+v"(resv[0][2]), "+v"(resv[0][3])::"memory");
                     asm volatile("" : "+v"(resv[1][0]), "+v"(resv[1][1]), "+v"(resv[1][2]), "+v"(resv[1][3])::"memory");
                 } else {
+#if RFD_PWG_EXP == 1 // timing only: the weight waves never wait (is the step waiting for the weight tile to land?)
+                    if (!is_w) wait_vmcnt<0>();
+#elif RFD_PWG_EXP == 2 // timing only: nobody waits
+#else
                     wait_vmcnt<0>();
+#endif
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
