@@ -344,6 +344,15 @@ RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
 RFD_API int rfd_debug_set_concurrency(rfd_ctx *ctx, int multi_stream, int split_min_part, int split_max_parts,
                                       int use_graph);
 
+/* Sets the device word through which a chunk workgroup of the dense-crowd NMS reports that it gave up waiting for its
+ * predecessor (tests: the next call that synchronises must then fail with RFD_ERR_HIP and clear the word). */
+RFD_API int rfd_debug_poke_nms_flag(rfd_ctx *ctx, int value);
+/* The list of PERSISTENT kernels (one workgroup per CU, looping over work items) and the dynamic LDS every launch of one
+ * requests -- always the CU's whole 160 KiB, so that no other kernel's workgroup can share the CU.
+ * Needs no context and no GPU: tests/test_build_cpu.py walks it against the kernels of the code object.  Returns the number
+ * of entries; fills name / lds_bytes for 0 <= i < that number. */
+RFD_API int rfd_debug_persistent_kernel(int i, const char **name, size_t *lds_bytes);
+
 #ifdef __cplusplus
 }
 #endif

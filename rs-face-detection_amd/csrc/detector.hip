@@ -114,7 +114,8 @@ static int rccl_load()
         }
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) {
-        set_error("librccl could not be loaded (%s); set RFD_RCCL_LIB", dlerror());
+        const char *why = dlerror(); // NULL when the last attempt was a NOLOAD probe that found nothing
+        set_error("librccl could not be loaded (%s); set RFD_RCCL_LIB", why ? why : "not found on the loader path");
         return RFD_ERR_COMM;
     }
     Rccl r;
@@ -128,6 +129,7 @@ static int rccl_load()
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
         set_error("the loaded librccl lacks a required entry point");
+        (void)dlclose(h); // do not keep a handle per failed attempt
         return RFD_ERR_COMM;
     }
     r.ok = true;
@@ -179,6 +181,9 @@ struct rfd_ctx {
     DevBuf nms_kept, nms_state; // chunked NMS (dense crowds): kept-box lists, per-chunk {count, epoch} + the spin_fail word
     int nms_epoch = 0;
     bool nms_chunked = true; // RFD_NMS_CHUNKED=0: one workgroup per image always (A/B and fallback)
+    // host mirror (page-locked) of the chunked NMS's spin_fail word: copied stream-ordered behind every NMS launch, looked at
+    // wherever the host synchronises with the stream (check_nms_flag)
+    int *h_nms_flag = nullptr;
     DevBuf out_boxes, out_lmk, out_count, out_total, out_gidx;
     DevBuf scratch[12];
     DevBuf sel_dims, sel_out;
@@ -353,7 +358,25 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
     }
     RFD_TRY(launch_nms(np, n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[6], c->stream));
+    // the device word is sticky (the kernel only ever sets it), so a later call's copy cannot hide an earlier give-up
+    if (np.spin_fail) RFD_HIP(hipMemcpyAsync(c->h_nms_flag, np.spin_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return RFD_OK;
+}
+
+// Call after the host has synchronised with c->stream.  A chunk workgroup of nms_chunked_kernel that gave up waiting for its
+// predecessor (bounded spin; forward progress rests on in-order workgroup dispatch, which the hardware does not promise)
+// produced a wrong kept set: that is an error, as every failure of the reference's call is an Err (face_detection.rs:498-509),
+// never RFD_OK with wrong detections.
+int check_nms_flag(rfd_ctx *c)
+{
+    if (!c->h_nms_flag || *c->h_nms_flag == 0) return RFD_OK;
+    *c->h_nms_flag = 0;
+    int *flag = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
+    RFD_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    set_error("chunked NMS: a workgroup timed out waiting for its predecessor chunk; the detections of the batches since the "
+              "last synchronisation are invalid (re-submit them; RFD_NMS_CHUNKED=0 selects the one-workgroup-per-image kernel)");
+    return RFD_ERR_HIP;
 }
 
 int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
@@ -453,8 +476,13 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         status = launch_preprocess(pp, Bp, st[p]);
         if (status == RFD_OK && p == 1 && net.chain_shift_op >= 0 && net.chain_shift_op < (int)net.g.ops.size() &&
             hipStreamWaitEvent(st[1], net.ev_shift, 0) != hipSuccess) status = RFD_ERR_HIP;
-        if (status == RFD_OK) status = net.run(Bp, st[p], 0, -1, off, p);
-        if (status == RFD_OK && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
+        if (status == RFD_OK) status = net.run(Bp, st[p], 0, net.hybrid_join > 0 ? net.hybrid_join - 1 : -1, off, p);
+        if (status == RFD_OK && net.hybrid_join <= 0 && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
+    }
+    if (status == RFD_OK && net.hybrid_join > 0) { // hybrid split: the small-M range runs once over the whole batch (Network::hybrid_tail)
+        status = net.hybrid_tail(n, B0, st[0], st[1]);
+        for (int p = 0; p < 2 && status == RFD_OK; ++p)
+            if (hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
     }
     net.co_running = 0;
     if (status != RFD_OK) { net.head_parity = 0; c->ov_last_n = -1; return status; }
@@ -514,6 +542,7 @@ int detect_impl(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, bool on
     RFD_HIP(hipEventRecord(c->ev[7], c->stream));
     if (async && on_device) return RFD_OK;
     RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_TRY(check_nms_flag(c));
     RFD_TRY(finish_stats(c, n, true, true));
     if (!on_device)
         for (int i = 0; i < n; ++i) c->stats.detections += out->total ? out->total[i] : out->count[i];
@@ -594,6 +623,8 @@ int rfd_create(const rfd_config *cfg, rfd_ctx **out)
             hipEventCreate(&c->pin_done[i]) != hipSuccess)
             st = RFD_ERR_HIP;
     }
+    if (st == RFD_OK && hipHostMalloc((void **)&c->h_nms_flag, sizeof(int)) != hipSuccess) st = RFD_ERR_HIP;
+    if (st == RFD_OK) *c->h_nms_flag = 0;
     if (st == RFD_OK) st = ctx_alloc(c);
     if (st != RFD_OK) {
         if (st == RFD_ERR_HIP && !*get_error()) set_error("HIP stream/event creation failed");
@@ -625,6 +656,7 @@ void rfd_destroy(rfd_ctx *c)
         if (c->pin_scales[i]) (void)hipHostFree(c->pin_scales[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
     }
+    if (c->h_nms_flag) (void)hipHostFree(c->h_nms_flag);
     for (rfd_ctx::PipeSlot &ps : c->pipe) {
         DevBuf *pb[] = {&ps.frames, &ps.imgs, &ps.scale, &ps.ob, &ps.ol, &ps.oc, &ps.ot};
         for (DevBuf *b : pb) b->release();
@@ -815,6 +847,16 @@ int rfd_debug_set_concurrency(rfd_ctx *c, int multi_stream, int split_min_part, 
         if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
     return RFD_OK;
 }
+int rfd_debug_poke_nms_flag(rfd_ctx *c, int value)
+{
+    RFD_CHECK_ARG(c, "ctx is null");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    int *flag = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
+    RFD_HIP(hipMemcpyAsync(flag, &value, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    RFD_HIP(hipStreamSynchronize(c->stream));
+    return RFD_OK;
+}
+int rfd_debug_persistent_kernel(int i, const char **name, size_t *lds_bytes) { return rfd::persistent_kernel_table(i, name, lds_bytes); }
 int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
 {
     RFD_CHECK_ARG(c, "ctx is null");
@@ -963,7 +1005,7 @@ int rfd_sync(rfd_ctx *c)
 {
     RFD_CHECK_ARG(c, "ctx is null");
     RFD_HIP(hipStreamSynchronize(c->stream));
-    return RFD_OK;
+    return check_nms_flag(c);
 }
 
 // ---- multi-GPU gather ----
@@ -1133,6 +1175,11 @@ int rfd_collect_batch(rfd_ctx *c, rfd_dets *out, int *n_out)
     if (c->pipe_inflight <= 0) { set_error("no batch in flight"); return RFD_ERR_STATE; }
     rfd_ctx::PipeSlot &ps = c->pipe[c->pipe_tail];
     RFD_HIP(hipEventSynchronize(ps.done));
+    if (*c->h_nms_flag) { // drop the batch: its detections cannot be trusted
+        c->pipe_tail = (c->pipe_tail + 1) % rfd_ctx::kPipe;
+        --c->pipe_inflight;
+        return check_nms_flag(c);
+    }
     const size_t MD = (size_t)c->cfg.max_det;
     for (int i = 0; i < ps.n; ++i) {
         const int k = ps.h_oc[i];
@@ -1231,6 +1278,7 @@ int rfd_decode_nms(rfd_ctx *c, const float *const heads[9], int n, const float *
     if (gidx) RFD_HIP(hipMemcpyAsync(gidx, c->out_gidx.p, n * MD * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipEventRecord(c->ev[7], c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
+    RFD_TRY(check_nms_flag(c));
     RFD_TRY(finish_stats(c, n, false, false));
     for (int i = 0; i < n; ++i) c->stats.detections += out->total ? out->total[i] : out->count[i];
     return RFD_OK;
@@ -1274,7 +1322,7 @@ static int select_impl(rfd_ctx *c, const float *d_boxes, const float *d_lmk, con
     RFD_HIP(hipMemcpyAsync(out_kps, sp.out_kps, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipMemcpyAsync(found, sp.out_found, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream)); // dims is a host temporary
-    return RFD_OK;
+    return check_nms_flag(c);
 }
 
 int rfd_select_faces(rfd_ctx *c, const rfd_dets *dets, const int *img_h, const int *img_w, int n,
@@ -1342,7 +1390,7 @@ static int align_impl(rfd_ctx *c, int n, const float *d_box, const float *d_kps,
     RFD_HIP(hipMemcpyAsync(out_crops, ap.out, (size_t)n * crop, hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipMemcpyAsync(status, ap.status, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
-    return RFD_OK;
+    return check_nms_flag(c);
 }
 
 int rfd_align_faces(rfd_ctx *c, const rfd_image *imgs, int n, const float *boxes, const float *kps, const int32_t *found,

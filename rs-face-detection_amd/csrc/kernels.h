@@ -140,6 +140,8 @@ struct ConvParams {
     int k_chunk_major;    // set by launch_conv: K order (chunk, ky, kx) instead of (ky, kx, chunk) (see conv_igemm_kernel)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);
+// entry i of the list of persistent kernels (name prefix, dynamic LDS every launch of it requests); returns the list length
+int persistent_kernel_table(int i, const char **name, size_t *lds_bytes);
 // back-to-back fusion (stage 1): raw = conv3(x) [+ 1x1 shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw*scale+shift)) + bias1)
 struct B2BParams {
     const bf16_t *x, *x2;      // [M][Cin], optional [M][Cin2] (stride-1 shortcut source)

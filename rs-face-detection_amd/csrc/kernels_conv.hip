@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
         if (NSX > 2 && kt + 1 < nk) wait_vmcnt<XP>();
         else wait_vmcnt<0>();
         // ... in every wave; the same barrier frees the slots consumed in step kt-1 for restaging
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
         if (kt + 1 < nk) {
             stage_w(wstage);
             wstage ^= 1;
@@ -488,8 +488,9 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 
     for (int mt = blockIdx.x; mt < tiles_m; mt += gridDim.x) {
         const int m0 = mt * BM;
-        // every wave is done with the previous tile's activation tile
-        asm volatile("s_barrier" ::: "memory");
+        // every wave is done with the previous tile's activation tile -- including fragment reads the compiler sank below their
+        // MFMAs: an LDS read still in flight at the barrier would race with the DMA that refills its slot
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // activation tile: NK K-steps x 16 pieces; wave w stages pieces w and w + 8 of every step
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt)
@@ -509,8 +510,10 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) {
                 // everything this step reads was drained by every wave before it got here; the barrier publishes it and
-                // frees the ring slot read one step ago for the matching K-step of the NEXT chunk
-                asm volatile("s_barrier" ::: "memory");
+                // frees the ring slot read one step ago for the matching K-step of the NEXT chunk (lgkmcnt(0): hipcc sinks the
+                // last ds_read pair of step kt-1 below that step's MFMAs, and a bare barrier would let issue_w() overwrite the
+                // slot while they are still in flight -- a write-after-read race found in the round-2 ISA)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue_w();
                 const bf16_t *xs = Xs + kt * BM * 64 + (wm * 32) * 64;
                 const bf16_t *ws = Ws + cslot * 128 * 64 + (wn * 64) * 64;
@@ -593,45 +596,76 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
     wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
 }
 
+// CU count of the current device, queried once per device (every persistent launcher sizes its "even share, no tail" grid
+// with it; a partitioned or smaller device simply gets a smaller grid)
+static int device_cus()
+{
+    static std::atomic<int> cached[DynLdsOnce::kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DynLdsOnce::kMaxDevices) return 256;
+    int n = cached[dev].load(std::memory_order_acquire);
+    if (n > 0) return n;
+    hipDeviceProp_t pr;
+    n = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    cached[dev].store(n, std::memory_order_release);
+    return n;
+}
+
 // CUs a persistent kernel spreads over when another chain of the same pass runs beside it (RFD_PERSIST_CUS: A/B knob;
 // default: all of them)
 static int persistent_cus(int co_running, bool hbm_bound = false)
 {
     static const int env = [] { const char *e = getenv("RFD_PERSIST_CUS"); return e ? atoi(e) : 0; }();
     static const int env_hbm = [] { const char *e = getenv("RFD_PERSIST_CUS_HBM"); return e ? atoi(e) : 0; }(); // HBM-bound kernels only
-    if (co_running && hbm_bound && env_hbm > 0) return env_hbm;
-    return co_running && env > 0 ? env : 256;
+    const int ncu = device_cus();
+    if (co_running && hbm_bound && env_hbm > 0) return std::min(env_hbm, ncu);
+    return co_running && env > 0 ? std::min(env, ncu) : ncu;
+}
+
+// ---- the one launch path of every persistent kernel ----
+// A persistent workgroup must own its CU's LDS (rule 2): whatever the kernel needs, the launch asks for
+// the whole 160 KiB, so no workgroup of another kernel can ever share the CU.  kPersistentKernels is the list the CPU build test
+// walks (tests/test_build_cpu.py, through rfd_debug_persistent_kernel): every 8-wave LDS-DMA kernel of the code object is either
+// in it or named there as one-tile-per-workgroup.  RFD_PERSIST_LDS_EXACT=1 (diagnostic only, tools/split_diag.py) requests the
+// real need instead -- the configuration that gave nondeterministic images in round 2.
+constexpr size_t kPersistentLds = 160 * 1024;
+static const char *const kPersistentKernels[] = {"pw_stream_kernel", "conv3x3_c64_kernel", "conv3x3_halo_kernel", "pw_gemm_kernel",
+                                                 "pw_wide_kernel", "conv_b2b_s1_persistent_kernel", "conv_b2b_s1_persistent_k128_kernel"};
+int persistent_kernel_table(int i, const char **name, size_t *lds_bytes)
+{
+    const int n = (int)(sizeof(kPersistentKernels) / sizeof(kPersistentKernels[0]));
+    if (i < 0 || i >= n) return n;
+    if (name) *name = kPersistentKernels[i];
+    if (lds_bytes) *lds_bytes = kPersistentLds;
+    return n;
+}
+template <auto Kern, typename... A> static int launch_persistent(int grid, size_t lds_need, hipStream_t s, A... args)
+{
+    static const bool exact = [] { const char *e = getenv("RFD_PERSIST_LDS_EXACT"); return e && atoi(e) != 0; }();
+    if (lds_need > kPersistentLds) { set_error("persistent kernel: %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(Kern), (int)kPersistentLds));
+    hipLaunchKernelGGL(Kern, dim3(grid), dim3(512), exact ? lds_need : kPersistentLds, s, args...);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
 }
 
 template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
-    int dev = 0, ncu = 256;
-    RFD_HIP(hipGetDevice(&dev));
-    static int cu_count[DynLdsOnce::kMaxDevices] = {};
-    if (dev >= 0 && dev < DynLdsOnce::kMaxDevices) {
-        if (!cu_count[dev]) { hipDeviceProp_t pr; RFD_HIP(hipGetDeviceProperties(&pr, dev)); cu_count[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-        ncu = cu_count[dev];
-    }
-    if (persistent_cus(p.co_running, true) < ncu) ncu = persistent_cus(p.co_running, true);
+    const int ncu = persistent_cus(p.co_running, true);
     // one persistent workgroup per CU; tiles are dealt round-robin, so an even share per workgroup means no tail
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    // The kernel needs (2 NK + 1) x 16 KiB + 12 B per output channel (86 KiB at K = 128, 156 KiB at K = 256) but always asks
-    // for the CU's whole LDS: a persistent workgroup must not share its CU with workgroups of ANOTHER kernel.  At 86 KiB the
-    // K = 128 variant co-resided with the other chain's 3x3 workgroups in the split mode, and exactly that configuration
-    // produced nondeterministic outputs (2-3 images of a 16-image part wrong in 5 of 8 passes; never with the 156 KiB variant,
-    // never once the request was padded: gpurun_out/r2_splitdiag5.txt) -- the same family as the round-1
-    // observation that LDS reads go wrong next to MFMA waves of another kernel.
+    // The kernel needs (2 NK + 1) x 16 KiB + 12 B per output channel (86 KiB at K = 128, 156 KiB at K = 256); launch_persistent
+    // asks for the CU's whole LDS.  At 86 KiB the K = 128 variant co-resided with the other chain's 3x3 workgroups in the split
+    // mode, and that configuration produced nondeterministic outputs in round 2 (2-3 images of a 16-image part wrong in 5 of 8
+    // passes; never with the 156 KiB variant, never once the request was padded: DESIGN.md section 5).  Round 3 found a
+    // write-after-read race on the weight ring in this kernel's ISA (bare s_barrier with ds_reads in flight, now
+    // `s_waitcnt lgkmcnt(0)` + barrier) that the padding may only have masked; the padding stays as the rule either way.
     const size_t lds_need = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
-    const size_t lds = 160 * 1024;
-    if (lds_need > lds) { set_error("pw_stream: %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
-    static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_stream_kernel<NK, HAS_Y, HAS_Y2>), 160 * 1024));
-    hipLaunchKernelGGL((pw_stream_kernel<NK, HAS_Y, HAS_Y2>), dim3(grid), dim3(512), lds, s, p);
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    return launch_persistent<pw_stream_kernel<NK, HAS_Y, HAS_Y2>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -759,7 +793,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
             // (X(g+1), issued behind W) allowed to stay in flight across the barrier.
             if (kx == 1 && g + 1 < ngroups) wait_vmcnt<XPE>();
             else wait_vmcnt<0>();
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
             if (kx < 2) stage_w(wslot ^ 1, ky, kc, kx + 1);
             else if (g + 1 < ngroups) stage_w(wslot ^ 1, nky, nkc, 0);
             if (kx == 0 && g + 1 < ngroups) stage_x(xslot ^ 1, nky, nkc);
@@ -878,7 +912,7 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, in
         // this tile's halo (and, the first time, the filter bank) has landed in every wave (drained below, before the
         // previous tile's stores were issued); the other buffer is free
         if (tile == (int)blockIdx.x) wait_vmcnt<0>();
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
         if (next < ntiles) stage_halo(next, buf ^ 1);
         const bf16_t *xb = xbase + buf * (kC64HP * 512);
         f32x4 acc[2][4];
@@ -941,14 +975,10 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
     const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(ntiles, ncu);
     const int grid = ceil_div(ntiles, per); // even share per persistent workgroup: no tail
-    // needs 154 KiB; asks for the whole CU's LDS so that no other kernel's workgroup can ever share the CU (see launch_pw_stream)
-    static_assert((size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t) <= 160 * 1024, "LDS");
-    const size_t lds = 160 * 1024;
-    static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv3x3_c64_kernel), (int)lds));
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y);
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    // needs 154 KiB; launch_persistent asks for the whole CU's LDS so that no other kernel's workgroup can ever share the CU
+    constexpr size_t lds_need = (size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t);
+    static_assert(lds_need <= kPersistentLds, "LDS");
+    return launch_persistent<conv3x3_c64_kernel>(grid, lds_need, s, p, tiles_x, tiles_y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1206,13 +1236,9 @@ template <int TC, int TR, int TN> static int launch_conv3x3_halo(const ConvParam
     const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
-    const size_t lds = 160 * 1024; // the whole CU, always: see launch_pw_stream
-    auto kern = conv3x3_halo_kernel<TC, TR, TN>;
-    static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y, n_items);
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    constexpr int HP = ((TR + 2) * (TC + 2) + 7) / 8, U = TN == 4 ? 2 : 1;
+    constexpr size_t lds_need = (size_t)(2 * HP * 512 + 2 * U * 32 * TN * 64) * 2 + 2048; // two halo buffers, two weight slots, tables
+    return launch_persistent<conv3x3_halo_kernel<TC, TR, TN>>(grid, lds_need, s, p, tiles_x, tiles_y, n_items);
 }
 
 template <int BN, int WAVES_M, int WAVES_N>
@@ -1492,12 +1518,8 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
 
 template <bool AFF, bool WIDE> static int launch_pw_gemm_t(const ConvParams &p, hipStream_t s, int tiles_m, int n_items, int grid)
 {
-    const size_t lds = 160 * 1024; // 3 activation + 2 weight slots + tables; the whole CU, always (see launch_pw_stream)
-    static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_gemm_kernel<AFF, WIDE>), (int)lds));
-    hipLaunchKernelGGL((pw_gemm_kernel<AFF, WIDE>), dim3(grid), dim3(512), lds, s, p, tiles_m, n_items);
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    // 3 activation + 2 weight slots + tables: the whole CU
+    return launch_persistent<pw_gemm_kernel<AFF, WIDE>>(grid, kPersistentLds, s, p, tiles_m, n_items);
 }
 
 static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
@@ -1728,12 +1750,8 @@ static int launch_pw_wide(const ConvParams &p, hipStream_t s)
     const int ncu = persistent_cus(p.co_running);
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
-    const size_t lds = 160 * 1024; // 4 x 32 KiB + tables; the whole CU, always (see launch_pw_stream)
-    static DynLdsOnce once;
-    RFD_TRY(once.ensure(reinterpret_cast<const void *>(pw_wide_kernel), (int)lds));
-    hipLaunchKernelGGL(pw_wide_kernel, dim3(grid), dim3(512), lds, s, p, n_items);
-    RFD_HIP(hipGetLastError());
-    return RFD_OK;
+    // 4 x 32 KiB + tables: the whole CU
+    return launch_persistent<pw_wide_kernel>(grid, kPersistentLds, s, p, n_items);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1815,7 +1833,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk1; ++kt) {
         wait_vmcnt<0>();
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
         const bf16_t *xs = Xs + (wm * 64) * 64, *ws = W3s + (wn * 64) * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1831,7 +1849,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk1) {
-            asm volatile("s_barrier" ::: "memory"); // every wave is done with the slot
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */ // every wave is done with the slot
             stage1(kt + 1);
         }
     }
@@ -2246,20 +2264,12 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
         const int per = ceil_div(ntiles, persistent_cus(1, true));
         const int grid = ceil_div(ntiles, per);
-        static DynLdsOnce once_p;
-        RFD_TRY(once_p.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_kernel), 160 * 1024));
-        hipLaunchKernelGGL(conv_b2b_s1_persistent_kernel, dim3(grid), dim3(512), 160 * 1024, s, p, ntiles); // the whole CU
-        RFD_HIP(hipGetLastError());
-        return RFD_OK;
+        return launch_persistent<conv_b2b_s1_persistent_kernel>(grid, kPersistentLds, s, p, ntiles);
     }
     // K1 = 128 (fused shortcut, no residual): persistent 64-pixel tiles, both filter banks resident
     if (p.Cin2 == 64 && !p.res && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (M >= 64 * 1024 || p.force_tile == 6)) {
         const int nt = ceil_div(M, 64), per = ceil_div(nt, persistent_cus(1, true));
-        static DynLdsOnce once_k;
-        RFD_TRY(once_k.ensure(reinterpret_cast<const void *>(conv_b2b_s1_persistent_k128_kernel), 160 * 1024));
-        hipLaunchKernelGGL(conv_b2b_s1_persistent_k128_kernel, dim3(ceil_div(nt, per)), dim3(512), 160 * 1024, s, p, nt);
-        RFD_HIP(hipGetLastError());
-        return RFD_OK;
+        return launch_persistent<conv_b2b_s1_persistent_k128_kernel>(ceil_div(nt, per), kPersistentLds, s, p, nt);
     }
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv_b2b_s1_kernel), (int)lds));
@@ -2508,7 +2518,10 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
 {
     __shared__ __attribute__((aligned(16))) uint2 in_tile[kStemIR * kStemIP];
     __shared__ __attribute__((aligned(16))) bf16_t conv_tile[kStemCR * kStemCC * kStemCP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15, fq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    // scalar wave index: the loops over `wave` below are then scalar loops in the ISA, i.e. their 128-bit LDS reads provably
+    // run with EXEC all ones (tools/isa_check.py, tests/test_build_cpu.py)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ho = H >> 1, Wo = W >> 1, Hp = Ho >> 1, Wp = Wo >> 1;
     int bid = blockIdx.x;
     const int tw = bid % tiles_w; bid /= tiles_w;
@@ -2530,12 +2543,13 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
     }
     // input patch -> LDS (zero outside the image)
     const uint2 *src = reinterpret_cast<const uint2 *>(x4) + (size_t)b * H * W;
-    for (int i = tid; i < kStemIR * kStemIP; i += 256) {
+    for (int round = 0; round < (kStemIR * kStemIP + 255) / 256; ++round) { // scalar trip count, predicated body
+        const int i = tid + round * 256;
         const int r = i / kStemIP, c = i - r * kStemIP;
         const int gr = ir0 + r, gc = ic0 + c;
         uint2 v = make_uint2(0, 0);
         if (c < kStemIC && (unsigned)gr < (unsigned)H && (unsigned)gc < (unsigned)W) v = src[(size_t)gr * W + gc];
-        in_tile[i] = v;
+        if (i < kStemIR * kStemIP) in_tile[i] = v;
     }
     __syncthreads();
 
@@ -2564,24 +2578,28 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
         }
         if (t * 16 + frow < NPIX) {
             const int gr = cr0 + cr, gc = cc0 + cc;
-            const bool inside = (unsigned)gr < (unsigned)Ho && (unsigned)gc < (unsigned)Wo;
+            // out-of-image conv pixels become +0 by masking the packed bits (a select per value compiled into a branch each)
+            const uint32_t inside = ((unsigned)gr < (unsigned)Ho && (unsigned)gc < (unsigned)Wo) ? 0xffffffffu : 0u;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float o[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    o[k] = inside ? fmaxf(acc[2 * h][k] + bv[h][k], 0.f) : 0.f;
-                    o[4 + k] = inside ? fmaxf(acc[2 * h + 1][k] + bv[h][4 + k], 0.f) : 0.f;
+                    o[k] = fmaxf(acc[2 * h][k] + bv[h][k], 0.f);
+                    o[4 + k] = fmaxf(acc[2 * h + 1][k] + bv[h][4 + k], 0.f);
                 }
                 const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                *reinterpret_cast<uint4 *>(conv_tile + idx * kStemCP + h * 32 + fq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                *reinterpret_cast<uint4 *>(conv_tile + idx * kStemCP + h * 32 + fq * 8) =
+                    make_uint4(lo.x & inside, lo.y & inside, hi.x & inside, hi.y & inside);
             }
         }
     }
     __syncthreads();
 
     // 3x3/2 max pool over the conv tile, then affine + ReLU; 8 channels (16 bytes) per item
-    for (int item = tid; item < kStemPH * kStemPW * 8; item += 256) {
+    static_assert(kStemPH * kStemPW * 8 % 256 == 0, "the pooling pass runs whole rounds of the workgroup (a scalar trip count)");
+    for (int round = 0; round < kStemPH * kStemPW * 8 / 256; ++round) {
+        const int item = tid + round * 256;
         const int c8 = item & 7, pp = item >> 3;
         const int pr = pp / kStemPW, pc = pp - pr * kStemPW;
         // no early `continue`: the ds_read_b128 below must run with EXEC all ones ("a hardware
@@ -2602,6 +2620,9 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
 #pragma unroll
                 for (int k = 0; k < 4; ++k) mi[k] = __builtin_elementwise_max(mi[k], __builtin_bit_cast(i16x2, u[k]));
             }
+        // pin the reads above the `if (live)`: hipcc otherwise sinks the whole body, reads included, under the store's predicate
+        // (seen in the round-3 ISA audit, tools/isa_check.py) -- a volatile asm cannot move into a conditional block
+        asm volatile("" : "+v"(mi[0]), "+v"(mi[1]), "+v"(mi[2]), "+v"(mi[3]));
         float mx[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

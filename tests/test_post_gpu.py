@@ -74,6 +74,69 @@ def test_mixed_batch_dense_and_sparse_images(rfd, oracle):
     d.close()
 
 
+def test_config5_dense_crowd_at_its_real_batch(rfd, oracle):
+    """BASELINE.json configs[4] at its stated size: 64 dense-crowd images (16 distinct ones, each ~12 k candidates and > 500
+    planted faces, four times in shuffled slots) in ONE launch -- 256 chunk workgroups of nms_chunked_kernel on 256 CUs, every one
+    of which spins on its predecessor's progress word: the occupancy at which the hand-over protocol is most exposed.  Identical
+    kept-anchor sequences per image against the oracle (nms.rs:3-65 semantics), and the spin_fail word stayed clear (a set
+    word makes rfd_decode_nms fail)."""
+    d = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=64, max_det=16800)
+    base = helpers.make_heads(41, 16, cand_rate=0.7, n_faces=600)
+    perm = np.random.default_rng(42).permutation(64) % 16
+    heads = [h[perm] for h in base]
+    sc = np.full(64, 1 / 6, np.float32)           # 3840x2160 sources (SURVEY Appendix C)
+    for rep in range(2):                          # twice: the second launch must not be satisfied by the first one's epochs
+        got = d.decode_nms(heads, sc, want_gidx=True)
+        ref = {}
+        for b in range(64):
+            i = int(perm[b])
+            if i not in ref:
+                ref[i] = oracle.decode_nms([h[i] for h in base], 640, 640, 0.7, 0.45, det_scale=1 / 6)
+            odet, olmk, ogidx, ncand = ref[i]
+            gdet, glmk, ggidx = got[b]
+            assert ncand > 11000 and len(ogidx) > 500
+            assert np.array_equal(ggidx, ogidx), "kept index sequence differs (slot %d = image %d)" % (b, i)
+            assert np.array_equal(gdet[:, 4], odet[:, 4])
+            np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=ATOL)
+            np.testing.assert_allclose(glmk, olmk, rtol=0, atol=ATOL)
+    assert d.stats()["candidates"] > 64 * 11000
+    d.close()
+
+
+def test_all_anchors_pass_at_batch_64(rfd, oracle):
+    """The worst case (every one of the 16 800 anchors is a candidate) on all 64 slots at once; 4 distinct images."""
+    d = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=64, max_det=16800)
+    base = helpers.make_heads(43, 4, cand_rate=1.0)
+    heads = [np.concatenate([h] * 16) for h in base]
+    got = d.decode_nms(heads, np.ones(64, np.float32), want_gidx=True)
+    ref = [oracle.decode_nms([h[i] for h in base], 640, 640, 0.7, 0.45, det_scale=1.0) for i in range(4)]
+    for b in range(64):
+        odet, olmk, ogidx, ncand = ref[b % 4]
+        assert ncand == 16800
+        assert np.array_equal(got[b][2], ogidx)
+        np.testing.assert_allclose(got[b][0], odet, rtol=0, atol=ATOL)
+    d.close()
+
+
+def test_nms_give_up_flag_is_an_error_not_wrong_detections(rfd, oracle):
+    """A chunk workgroup that times out waiting for its predecessor sets a device word; every call that synchronises reads it
+    back and fails (the reference returns Err on every failure, face_detection.rs:498-509) -- then clears it."""
+    d = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=2, max_det=2048)
+    heads = helpers.make_heads(44, 2, cand_rate=0.2, n_faces=50)
+    sc = np.ones(2, np.float32)
+    ok = d.decode_nms(heads, sc)
+    L = rfd.load_library()
+    assert L.rfd_debug_poke_nms_flag(d._ctx, 1) == 0
+    with pytest.raises(rfd.RfdError) as e:
+        d.decode_nms(heads, sc)
+    assert "NMS" in str(e.value)
+    again = d.decode_nms(heads, sc)               # the word was cleared: the same call succeeds and gives the same result
+    for (a, _), (b, _) in zip(ok, again):
+        assert np.array_equal(a, b)
+    assert e.value.status == rfd.RFD_ERR_HIP
+    d.close()
+
+
 def test_worst_case_all_anchors(rfd, oracle, det640):
     heads = helpers.make_heads(13, 1, cand_rate=1.0)
     _compare(oracle, det640, heads, 1, 640, 640, np.array([1.0], np.float32))
