@@ -157,20 +157,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
     }
 }
 
-#ifndef RFD_SAFE_WAITS
-#define RFD_SAFE_WAITS 0 // diagnostic build (-DRFD_SAFE_WAITS=1): every counted wait becomes a full drain
-#endif
+// Every wait on the vector-memory counter in this file is a FULL drain.  Rounds 1-2 shipped two counted waits (`vmcnt(XP)`: the
+// youngest activation tile allowed to stay in flight behind the weight tile, in conv_igemm_kernel and conv3x3_kx_kernel); a
+// build with drains everywhere measured the same end to end (7 583 / 7 615 vs 7 643 / 7 499 img/s, one box, round 3), so the
+// argument about when a counted wait is sound (rule 1) no longer has to carry any kernel.
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RFD_SAFE_WAITS ? 0 : N) : "memory");
+    static_assert(N == 0, "counted vmcnt waits are not used: drain");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // LDS operand rings: NSX slots for the activation (im2col) tile, 2 for the weight tile.  With NSX = 3 the
 // activation tile of step kt+2 is requested while step kt computes (HBM/L2 latency gets two steps of
-// cover), the L2-hot weight tile one step ahead; per step the weight DMAs are issued BEFORE the younger
-// activation DMAs, so a counted `s_waitcnt vmcnt(XP)` retires everything step kt needs and leaves the
-// activation tile kt+1 in flight across the barrier.  128x128: 3*16 + 2*16 = 80 KiB -> two workgroups
-// fill the CU's 160 KiB exactly.
+// cover), the L2-hot weight tile one step ahead; the one drain per step lands both (rounds 1-2 left the youngest
+// activation tile in flight behind a counted wait: no measurable difference, see wait_vmcnt).  128x128: 3*16 + 2*16 =
+// 80 KiB -> two workgroups fill the CU's 160 KiB exactly.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX, bool CHUNK_MAJOR = false>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
@@ -311,10 +312,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 
     int xslot = 0, wslot = 0, xstage = NSX - 1, wstage = 1;
     for (int kt = 0; kt < nk; ++kt) {
-        // step kt needs X(kt), W(kt): with the 3-slot X ring only X(kt+1) (the youngest XP DMAs of this
-        // wave) may still be in flight
-        if (NSX > 2 && kt + 1 < nk) wait_vmcnt<XP>();
-        else wait_vmcnt<0>();
+        // step kt needs X(kt), W(kt); the drain also lands X(kt+1) (3-slot ring), requested a whole step ago
+        wait_vmcnt<0>();
         // ... in every wave; the same barrier frees the slots consumed in step kt-1 for restaging
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
         if (kt + 1 < nk) {
@@ -383,10 +382,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const
 //     s_waitcnt vmcnt(0)        <- the ONLY wait: stores of c-1, residual of c, weights of c+1 -- all issued >= 1 step ago
 //     epilogue of c: request the residual of c+1 (registers, two alternating sets), + bias (LDS table), store c
 // so the stores of chunk c and the residual of c+1 travel while the MFMAs of c+1 run, and what the wait really waits for
-// is the HBM pipe itself.  Every wait is a full drain on purpose: a COUNTED vmcnt is only sound when the operations that
-// must have landed cannot be overtaken by younger ones, and LDS-DMA from L2 (weights) does overtake older LDS-DMA from HBM
-// (activations) -- a first version with counted waits returned stale activation tiles in the first chunk of ~3 % of the
-// tiles (tests/test_persistent_gpu.py).  The residual loads are inline asm (hipcc would otherwise
+// is the HBM pipe itself.  Every wait is a full drain on purpose: a first version with COUNTED waits returned stale
+// activation tiles in the first chunk of ~3 % of the tiles (tests/test_persistent_gpu.py).  It had the previous chunk's output
+// STORES in flight under its counted waits, and on this ISA loads and stores share vmcnt but retire out of order with respect
+// to each other -- the documented case in which only vmcnt(0) is sound (rule 1 as reworded in round 3;
+// round 2 had blamed L2-served DMA overtaking HBM-served DMA).  The residual loads are inline asm (hipcc would otherwise
 // place its own wait at an unknown point).  8 waves: 4 (pixels) x 2 (channels), 32 x 64 outputs each.
 // LDS: activation tile NK x 16 KiB + weight ring (NK + 1) x 16 KiB + 12 B per output channel: 156 KiB at K = 256.
 // ------------------------------------------------------------------------------------------------
@@ -789,10 +789,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
         if (nky == 3) { nky = 0; ++nkc; }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            // step (g, kx) needs W(this step) and X(g).  Only after the kx = 0 step are the XPE youngest DMAs
-            // (X(g+1), issued behind W) allowed to stay in flight across the barrier.
-            if (kx == 1 && g + 1 < ngroups) wait_vmcnt<XPE>();
-            else wait_vmcnt<0>();
+            // step (g, kx) needs W(this step) and X(g); X(g+1) was requested in the kx = 0 step and lands with this drain too
+            wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
             if (kx < 2) stage_w(wslot ^ 1, ky, kc, kx + 1);
             else if (g + 1 < ngroups) stage_w(wslot ^ 1, nky, nkc, 0);

@@ -97,8 +97,14 @@ def test_config5_dense_crowd_at_its_real_batch(rfd, oracle):
             assert ncand > 11000 and len(ogidx) > 500
             assert np.array_equal(ggidx, ogidx), "kept index sequence differs (slot %d = image %d)" % (b, i)
             assert np.array_equal(gdet[:, 4], odet[:, 4])
-            np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=ATOL)
-            np.testing.assert_allclose(glmk, olmk, rtol=0, atol=ATOL)
+            # 1e-4 is north_star's bar at the NETWORK scale; these rows are divided by det_scale = 1/6 (true f32 division,
+            # face_detection.rs:473-493), i.e. live at 4K coordinates where one f32 ulp is 2.4e-4.  Over 64 x 12 k decodes a
+            # handful of box sizes differ by that one ulp: the device's exp is correctly rounded ((float)exp((double)x)),
+            # glibc's expf -- what the oracle, like Rust's f32::exp, calls -- is not always (unpinned third-party arithmetic,
+            # SURVEY 8(c)).  First seen in round 3: 1 coordinate of 14 752 off by 1.2e-4 at x = 1 181.
+            np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=ATOL * 6)
+            np.testing.assert_allclose(glmk, olmk, rtol=0, atol=ATOL * 6)
+            assert np.mean(gdet[:, :4] == odet[:, :4]) > 0.999
     assert d.stats()["candidates"] > 64 * 11000
     d.close()
 
