@@ -57,6 +57,8 @@ typedef enum rfd_backbone {
  * model-config / model-name arguments are gone (the network runs in-process); device, batch
  * capacity and output capacity are new.
  */
+typedef enum rfd_precision { RFD_PRECISION_BF16 = 0, RFD_PRECISION_F32 = 1 } rfd_precision;
+
 typedef struct rfd_config {
     int image_w;                /* config.rs:26 image_size.0, default 640 */
     int image_h;                /* config.rs:26 image_size.1, default 640 */
@@ -68,7 +70,11 @@ typedef struct rfd_config {
     int max_src_w;              /* largest source frame the context must stage; default 3840 */
     int max_src_h;              /* default 2160 */
     int backbone;               /* rfd_backbone */
-    int reserved[6];
+    int precision;              /* rfd_precision: 0 = bf16 activations / weights with f32 accumulation (the product path,
+                                 * BASELINE.json configs[2]); 1 = the f32 parity mode (RetinaFace-R50 only): f32 weights,
+                                 * activations and accumulation, the reference's FP32 tensor contract (face_detection.rs:261).
+                                 * A correctness mode: plain FMA kernels, one stream, ~20x slower than the bf16 path. */
+    int reserved[5];
 } rfd_config;
 
 /* A decoded source frame: HxWx3 u8, BGR, row stride in bytes (an OpenCV Mat CV_8UC3,

@@ -70,7 +70,7 @@ class RetinaFaceDetection {
     // RetinaFaceDetection::new(client, model_cfg, model_name, image_size, max_batch_size, conf, iou) minus the Triton
     // arguments (face_detection.rs:41-49)
     RetinaFaceDetection(std::pair<int, int> image_size, int max_batch_size, float confidence_threshold, float iou_threshold,
-                        int device_id = 0, int max_det = 1024, int backbone = RFD_BACKBONE_R50)
+                        int device_id = 0, int max_det = 1024, int backbone = RFD_BACKBONE_R50, int precision = RFD_PRECISION_BF16)
     {
         rfd_config cfg;
         rfd_config_default(&cfg);
@@ -81,6 +81,7 @@ class RetinaFaceDetection {
         cfg.device_id = device_id;
         cfg.max_det = max_det;
         cfg.backbone = backbone;
+        cfg.precision = precision; // RFD_PRECISION_F32: the f32 parity mode (the reference's FP32 tensor contract, face_detection.rs:261)
         check(rfd_create(&cfg, &ctx_));
         max_det_ = (std::size_t)max_det;
         max_batch_ = max_batch_size;

@@ -229,7 +229,7 @@ struct rfd_ctx {
     int ensure_network()
     {
         if (net_created) return RFD_OK;
-        RFD_TRY(net.create(cfg.backbone, cfg.image_w, cfg.image_h, cfg.max_batch_size));
+        RFD_TRY(net.create(cfg.backbone, cfg.image_w, cfg.image_h, cfg.max_batch_size, cfg.precision));
         net_created = true;
         return RFD_OK;
     }
@@ -334,7 +334,7 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
     RFD_HIP(hipMemsetAsync(c->count.p, 0, n * sizeof(int), c->stream));
     RFD_TRY(launch_decode(dp, n, nchw, c->stream));
     RFD_HIP(hipEventRecord(c->ev[4], c->stream));
-    RFD_TRY(launch_sort((const uint64_t *)c->keys.p, (const int *)c->count.p, (const float *)c->rows.p,
+    RFD_TRY(launch_sort((uint64_t *)c->keys.p, (const int *)c->count.p, (const float *)c->rows.p,
                         (uint64_t *)c->sorted_keys.p, (float4 *)c->sorted_boxes.p, c->total_anchors, n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[5], c->stream));
     NmsParams np;
@@ -586,6 +586,8 @@ int rfd_create(const rfd_config *cfg, rfd_ctx **out)
                   "image_size must be positive multiples of 32");
     RFD_CHECK_ARG(cfg->max_batch_size >= 1, "max_batch_size < 1");
     RFD_CHECK_ARG(cfg->max_det >= 1, "max_det < 1");
+    RFD_CHECK_ARG(cfg->precision == RFD_PRECISION_BF16 || cfg->precision == RFD_PRECISION_F32, "precision must be RFD_PRECISION_BF16 or RFD_PRECISION_F32");
+    RFD_CHECK_ARG(cfg->precision == RFD_PRECISION_BF16 || cfg->backbone == RFD_BACKBONE_R50, "the f32 parity mode exists for RetinaFace-R50 only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no HIP device is available: librfd_hip has no CPU fallback");
@@ -821,6 +823,10 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
     RFD_CHECK_ARG(n >= 1 && n <= c->cfg.max_batch_size, "batch out of range");
     const size_t bytes = c->net.g.tensors[tensor_id].bytes_per_image() * (size_t)n;
     c->ov_last_n = -1;
+    if (c->net.precision != 0 && !c->net.g.tensors[tensor_id].is_f32 && tensor_id != c->net.g.input) {
+        set_error("f32 parity mode: intermediate tensors are f32, not the bf16 layout this hook transfers");
+        return RFD_ERR_STATE;
+    }
     if (write) RFD_HIP(hipMemcpyAsync(c->net.tensor_ptr(tensor_id), host, bytes, hipMemcpyHostToDevice, c->stream));
     else RFD_HIP(hipMemcpyAsync(host, c->net.tensor_ptr(tensor_id), bytes, hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));

@@ -43,7 +43,7 @@ struct DecodeParams {
 };
 int launch_decode(const DecodeParams &p, int n, bool nchw, hipStream_t s);
 
-int launch_sort(const uint64_t *keys, const int *count, const float *rows, uint64_t *sorted_keys,
+int launch_sort(uint64_t *keys, const int *count, const float *rows, uint64_t *sorted_keys,
                 float4 *sorted_boxes, int total_anchors, int n, hipStream_t s);
 
 struct NmsParams {
@@ -142,6 +142,23 @@ struct ConvParams {
 int launch_conv(const ConvParams &p, hipStream_t s);
 // entry i of the list of persistent kernels (name prefix, dynamic LDS every launch of it requests); returns the list length
 int persistent_kernel_table(int i, const char **name, size_t *lds_bytes);
+// ---- f32 parity mode (kernels_f32.hip): ConvParams with f32 tensors and weights; same field meanings ----
+struct ConvF32Params {
+    const float *x, *w, *x2;   // [B][H][W][ldx] (channel slice at x_coff), [Cout][ldw], optional [B][H2][W2][Cin2]
+    const float *bias, *bias2; // [Cout]; the fused shortcut's bias or null
+    const float *res;          // residual [B][RH][RW][Cout] or null
+    const float *in_scale, *in_shift, *scale2, *shift2;
+    float *y, *y2, *yf;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int H2, W2, Cin2, stride2;
+    int ldw;                   // weight row pitch in elements (KH*KW*Cin + Cin2)
+    int ldy, y_coff, ldx, x_coff, y_split, y_split_add, n_valid;
+    int relu, res_up2, res_post, head_softmax;
+};
+int launch_conv_f32(const ConvF32Params &p, hipStream_t s);
+int launch_conv0_f32(const bf16_t *x4, const float *w, const float *bias, float *y, int B, int H, int W, hipStream_t s);
+int launch_maxpool_f32(const float *x, float *y, const float *scale, const float *shift, int B, int H, int W, int C, hipStream_t s);
+
 // back-to-back fusion (stage 1): raw = conv3(x) [+ 1x1 shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw*scale+shift)) + bias1)
 struct B2BParams {
     const bf16_t *x, *x2;      // [M][Cin], optional [M][Cin2] (stride-1 shortcut source)

@@ -90,7 +90,22 @@ struct Network {
     std::vector<float> op_ms;   // last profiled run
     int prof_first = 0, prof_last = -1; // op range of the last run
 
-    int create(int backbone, int net_w, int net_h, int max_batch);
+    // f32 parity mode (rfd_config.precision = RFD_PRECISION_F32; kernels_f32.hip): f32 copies of the weights (same element
+    // offsets as d_w) and of the workspace buffers (same plan, 4 bytes per element); run() then walks the op list with the f32
+    // kernels on the caller's stream -- no batch split, no hipGraph, no persistent kernels.  Heads and the network input keep
+    // their ordinary buffers (f32 / exact bf16), so preprocess and decode are shared with the bf16 path.
+    int precision = 0;
+    float *d_w32 = nullptr;
+    void *d_stem32 = nullptr; // conv0 activation of the (unfused) f32 stem
+    std::vector<void *> d_buffers32;
+    void *tensor_ptr32(int t, int batch_off = 0) const
+    {
+        if (g.tensors[t].is_f32 || t == g.input) return tensor_ptr(t, batch_off);
+        const int bi = g.tensors[t].buffer;
+        return (char *)d_buffers32[bi] + (size_t)batch_off * g.buffer_bytes_per_image[bi] * 2;
+    }
+    int run_f32(int B, hipStream_t s, int first_op, int last_op, int batch_off);
+    int create(int backbone, int net_w, int net_h, int max_batch, int precision = 0);
     void destroy();
     int init_synthetic(uint64_t seed, hipStream_t s);
     int get_layer(int idx, float *w, float *bias, hipStream_t s);
@@ -160,7 +175,7 @@ struct Network {
     int split_max_parts = 2; // parts = clamp(B / split_min_part, 1, split_max_parts)
     int num_parts(int B) const
     {
-        if (profiling || split_min_part < 1) return 1;
+        if (profiling || split_min_part < 1 || precision != 0) return 1;
         return std::max(1, std::min(std::min(split_max_parts, kMaxParts), B / split_min_part));
     }
     int collect_profile(); // after the stream has drained

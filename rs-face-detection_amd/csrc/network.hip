@@ -394,10 +394,23 @@ double Graph::macs_per_image() const
 // ------------------------------------------------------------------------------------------------
 // Network
 // ------------------------------------------------------------------------------------------------
-int Network::create(int backbone, int net_w, int net_h, int max_batch_)
+int Network::create(int backbone, int net_w, int net_h, int max_batch_, int precision_)
 {
     RFD_TRY(g.build(backbone, net_w, net_h));
     max_batch = max_batch_;
+    precision = precision_;
+    if (precision != 0) {
+        for (const Op &o : g.ops)
+            if (o.kind == OP_DW || o.kind == OP_FIRST || o.kind == OP_CONV0) { set_error("f32 parity mode: this backbone has no f32 kernels (RetinaFace-R50 only)"); return RFD_ERR_INVALID_ARG; }
+        use_graph = false;
+        RFD_HIP(hipMalloc((void **)&d_w32, g.w_total * sizeof(float)));
+        RFD_HIP(hipMemset(d_w32, 0, g.w_total * sizeof(float)));
+        d_buffers32.assign(g.buffer_bytes_per_image.size(), nullptr);
+        for (size_t i = 0; i < d_buffers32.size(); ++i) {
+            RFD_HIP(hipMalloc(&d_buffers32[i], g.buffer_bytes_per_image[i] * 2 * (size_t)max_batch));
+            RFD_HIP(hipMemset(d_buffers32[i], 0, g.buffer_bytes_per_image[i] * 2 * (size_t)max_batch));
+        }
+    }
     RFD_HIP(hipMalloc((void **)&d_w, g.w_total * sizeof(bf16_t)));
     RFD_HIP(hipMalloc((void **)&d_b, (g.b_total + g.a_total) * sizeof(float))); // biases, then affines
     RFD_HIP(hipMemset(d_w, 0, g.w_total * sizeof(bf16_t)));
@@ -433,6 +446,13 @@ void Network::destroy()
     if (d_b) (void)hipFree(d_b);
     if (d_zero) (void)hipFree(d_zero);
     d_zero = nullptr;
+    if (d_w32) (void)hipFree(d_w32);
+    d_w32 = nullptr;
+    if (d_stem32) (void)hipFree(d_stem32);
+    d_stem32 = nullptr;
+    for (void *p : d_buffers32)
+        if (p) (void)hipFree(p);
+    d_buffers32.clear();
     for (void *p : d_buffers)
         if (p) (void)hipFree(p);
     for (void *p : d_alt)
@@ -571,6 +591,22 @@ int Network::set_layer(int idx, const float *w, const float *bias, hipStream_t s
     }
     RFD_HIP(hipMemcpy2DAsync(d_w + L.w_off, L.ldw * sizeof(bf16_t), hw.data(), K * sizeof(bf16_t), K * sizeof(bf16_t), rows,
                              hipMemcpyHostToDevice, s));
+    std::vector<float> hw32;
+    if (d_w32) { // f32 parity mode: the UNROUNDED values in the same device layout (conv0 and ordinary convs only: R50)
+        hw32.assign(rows * K, 0.f);
+        if (L.kind == LK_CONV0) {
+            for (int n = 0; n < L.cout; ++n)
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx)
+                        for (int c = 0; c < 3; ++c) hw32[((size_t)n * 7 + ky) * 32 + kx * 4 + c] = w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c];
+        } else if (L.kind == LK_CONV) {
+            for (int n = 0; n < L.cout; ++n)
+                for (int t = 0; t < taps; ++t)
+                    for (int c = 0; c < L.cin; ++c) hw32[(size_t)n * K + (size_t)t * L.cin_d + c] = w[((size_t)n * taps + t) * L.cin + c];
+        }
+        RFD_HIP(hipMemcpy2DAsync(d_w32 + L.w_off, L.ldw * sizeof(float), hw32.data(), K * sizeof(float), K * sizeof(float), rows,
+                                 hipMemcpyHostToDevice, s));
+    }
     std::vector<float> hb(L.cout_d, 0.f);
     if (bias) {
         memcpy(hb.data(), bias, L.cout * sizeof(float));
@@ -585,7 +621,23 @@ int Network::get_layer(int idx, float *w, float *bias, hipStream_t s)
     if (idx < 0 || idx >= (int)g.layers.size()) { set_error("layer index %d out of range", idx); return RFD_ERR_INVALID_ARG; }
     const Layer &L = g.layers[idx];
     const int taps = L.kh * L.kw;
-    if (w) {
+    if (w && d_w32 && (L.kind == LK_CONV0 || L.kind == LK_CONV)) { // f32 parity mode: the values the f32 kernels use
+        size_t rows = L.cout_d, K = (size_t)taps * L.cin_d;
+        if (L.kind == LK_CONV0) { rows = L.cout; K = 7 * 32; }
+        std::vector<float> hw(rows * K);
+        RFD_HIP(hipMemcpy2DAsync(hw.data(), K * sizeof(float), d_w32 + L.w_off, L.ldw * sizeof(float), K * sizeof(float), rows, hipMemcpyDeviceToHost, s));
+        RFD_HIP(hipStreamSynchronize(s));
+        if (L.kind == LK_CONV0) {
+            for (int n = 0; n < L.cout; ++n)
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx)
+                        for (int c = 0; c < 3; ++c) w[(((size_t)n * 7 + ky) * 7 + kx) * 3 + c] = hw[((size_t)n * 7 + ky) * 32 + kx * 4 + c];
+        } else {
+            for (int n = 0; n < L.cout; ++n)
+                for (int t = 0; t < taps; ++t)
+                    for (int c = 0; c < L.cin; ++c) w[((size_t)n * taps + t) * L.cin + c] = hw[(size_t)n * K + (size_t)t * L.cin_d + c];
+        }
+    } else if (w) {
         size_t rows = L.cout_d, K = (size_t)taps * L.cin_d;
         if (L.kind == LK_CONV0) { rows = L.cout; K = 7 * 32; }
         else if (L.kind == LK_FIRST3X3) { rows = L.cout; K = 36; }
@@ -645,6 +697,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
 {
     if (!weights_ready) { set_error("network weights are not initialised (rfd_init_synthetic_weights / rfd_set_layer_weights)"); return RFD_ERR_STATE; }
     if (B < 1 || batch_off + B > max_batch) { set_error("batch %d exceeds max_batch_size %d", batch_off + B, max_batch); return RFD_ERR_CAPACITY; }
+    if (precision != 0) return run_f32(B, s, first_op, last_op, batch_off);
     const int nops = (int)g.ops.size();
     if (profiling && (int)ev.size() < 2 * nops) {
         const size_t old = ev.size();
@@ -757,6 +810,89 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             RFD_HIP(hipEventRecord(ev_join[part][bidx], side[part][bidx]));
             RFD_HIP(hipStreamWaitEvent(main_stream, ev_join[part][bidx], 0));
         }
+    return RFD_OK;
+}
+
+// The op list in f32 (kernels_f32.hip): the same parameters run() builds, f32 pointers, one stream.  The fused stem runs as
+// conv0 -> max pool (+ affine + ReLU) through the stem's own output buffer region is NOT possible (different sizes), so the
+// conv0 activation goes to a scratch allocation made on first use; the stage-1 back-to-back op runs as its two convolutions.
+int Network::run_f32(int B, hipStream_t s, int first_op, int last_op, int batch_off)
+{
+    const int nops = (int)g.ops.size();
+    if (last_op < 0 || last_op >= nops) last_op = nops - 1;
+    const float *aff = d_b + g.b_total;
+    for (int i = std::max(first_op, 0); i <= last_op; ++i) {
+        const Op &o = g.ops[i];
+        const Layer &L = g.layers[o.layer];
+        const TensorDesc &tin = g.tensors[o.in];
+        if (o.kind == OP_STEM) {
+            const size_t need = (size_t)max_batch * (tin.H / 2) * (tin.W / 2) * 64 * sizeof(float);
+            if (!d_stem32) RFD_HIP(hipMalloc(&d_stem32, need));
+            float *c0 = (float *)d_stem32 + (size_t)batch_off * (tin.H / 2) * (tin.W / 2) * 64;
+            RFD_TRY(launch_conv0_f32((const bf16_t *)tensor_ptr(o.in, batch_off), d_w32 + L.w_off, d_b + L.b_off, c0, B, tin.H, tin.W, s));
+            RFD_TRY(launch_maxpool_f32(c0, (float *)tensor_ptr32(o.out, batch_off), aff + L.a_off, aff + L.a_off + L.cout_d, B, tin.H / 2,
+                                       tin.W / 2, 64, s));
+            continue;
+        }
+        if (o.kind == OP_POOL) {
+            RFD_TRY(launch_maxpool_f32((const float *)tensor_ptr32(o.in, batch_off), (float *)tensor_ptr32(o.out, batch_off), aff + L.a_off,
+                                       aff + L.a_off + L.cout_d, B, tin.H, tin.W, tin.C, s));
+            continue;
+        }
+        if (o.kind != OP_CONV && o.kind != OP_B2B) { set_error("f32 parity mode: op kind %d has no f32 kernel", o.kind); return RFD_ERR_INVALID_ARG; }
+        const int tout = o.out >= 0 ? o.out : (o.out2 >= 0 ? o.out2 : o.outf);
+        ConvF32Params p;
+        memset(&p, 0, sizeof p);
+        p.x = (const float *)tensor_ptr32(o.in, batch_off);
+        p.w = d_w32 + L.w_off;
+        p.ldw = (int)L.ldw;
+        p.bias = d_b + L.b_off;
+        p.res = o.res >= 0 ? (const float *)tensor_ptr32(o.res, batch_off) : nullptr;
+        if (o.layer2 >= 0) {
+            const Layer &L2 = g.layers[o.layer2];
+            const TensorDesc &t2 = g.tensors[o.in2];
+            p.x2 = (const float *)tensor_ptr32(o.in2, batch_off);
+            p.bias2 = d_b + L2.b_off;
+            p.H2 = t2.H; p.W2 = t2.W; p.Cin2 = L2.cin_d; p.stride2 = L2.stride;
+        }
+        if (o.in_affine >= 0) {
+            const Layer &La = g.layers[o.in_affine];
+            p.in_scale = aff + La.a_off;
+            p.in_shift = aff + La.a_off + La.cout_d;
+        }
+        p.scale2 = aff + L.a_off;
+        p.shift2 = aff + L.a_off + L.cout_d;
+        p.y = o.out >= 0 ? (float *)tensor_ptr32(o.out, batch_off) : nullptr;
+        p.y2 = o.out2 >= 0 ? (float *)tensor_ptr32(o.out2, batch_off) : nullptr;
+        p.yf = o.outf >= 0 ? (float *)tensor_ptr32(o.outf, batch_off) : nullptr;
+        p.B = B; p.H = tin.H; p.W = tin.W; p.Cin = L.cin_d;
+        p.Cout = L.cout_d + (o.layer_n2 >= 0 ? g.layers[o.layer_n2].cout_d : 0);
+        p.n_valid = o.n_valid;
+        p.ldx = tin.C; p.x_coff = o.x_coff; p.y_split = o.y_split; p.y_split_add = o.y_split_add;
+        p.KH = L.kh; p.KW = L.kw; p.stride = L.stride; p.pad = L.pad;
+        p.Ho = g.tensors[tout].H; p.Wo = g.tensors[tout].W;
+        p.ldy = o.out >= 0 ? g.tensors[o.out].C : p.Cout;
+        p.y_coff = o.y_coff;
+        p.relu = o.relu; p.res_up2 = o.res_up2; p.res_post = o.res_post; p.head_softmax = o.head_softmax;
+        if (o.kind == OP_B2B) { // raw = conv3(x) [+ shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw * scale + shift)) + bias1)
+            p.relu = 0; p.y2 = nullptr; p.yf = nullptr;
+            p.n_valid = p.Cout; p.y_split = 1 << 30; p.y_split_add = 0; p.y_coff = 0; p.ldy = p.Cout;
+            RFD_TRY(launch_conv_f32(p, s));
+            const Layer &Lb = g.layers[o.layer_b];
+            ConvF32Params q;
+            memset(&q, 0, sizeof q);
+            q.x = (const float *)tensor_ptr32(o.out, batch_off);
+            q.w = d_w32 + Lb.w_off; q.ldw = (int)Lb.ldw; q.bias = d_b + Lb.b_off;
+            q.in_scale = aff + L.a_off; q.in_shift = aff + L.a_off + L.cout_d;
+            q.y = (float *)tensor_ptr32(o.out_b, batch_off);
+            q.B = B; q.H = q.Ho = tin.H; q.W = q.Wo = tin.W; q.Cin = Lb.cin_d; q.Cout = Lb.cout_d;
+            q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
+            q.ldx = g.tensors[o.out].C; q.ldy = g.tensors[o.out_b].C; q.n_valid = q.Cout; q.y_split = 1 << 30; q.relu = 1;
+            RFD_TRY(launch_conv_f32(q, s));
+            continue;
+        }
+        RFD_TRY(launch_conv_f32(p, s));
+    }
     return RFD_OK;
 }
 

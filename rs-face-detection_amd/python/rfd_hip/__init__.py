@@ -15,6 +15,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "librfd_hip.so"))
 RFD_OK = 0
 RFD_ERR_INVALID_ARG = -1
 RFD_ERR_NO_DEVICE = -2
+PRECISION_BF16, PRECISION_F32 = 0, 1
 RFD_ERR_HIP = -3
 RFD_ERR_CAPACITY = -4
 RFD_ERR_STATE = -5
@@ -39,7 +40,7 @@ class rfd_config(C.Structure):
     _fields_ = [("image_w", C.c_int), ("image_h", C.c_int), ("max_batch_size", C.c_int),
                 ("confidence_threshold", C.c_float), ("iou_threshold", C.c_float),
                 ("device_id", C.c_int), ("max_det", C.c_int), ("max_src_w", C.c_int),
-                ("max_src_h", C.c_int), ("backbone", C.c_int), ("reserved", C.c_int * 6)]
+                ("max_src_h", C.c_int), ("backbone", C.c_int), ("precision", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class rfd_image(C.Structure):
@@ -257,7 +258,7 @@ class RetinaFaceDetection:
     """
 
     def __init__(self, image_size=(640, 640), max_batch_size=1, confidence_threshold=0.7,
-                 iou_threshold=0.45, device_id=0, max_det=1024, backbone=BACKBONE_R50):
+                 iou_threshold=0.45, device_id=0, max_det=1024, backbone=BACKBONE_R50, precision=0):
         self._L = load_library()
         cfg = rfd_config()
         self._L.rfd_config_default(C.byref(cfg))
@@ -265,6 +266,7 @@ class RetinaFaceDetection:
         cfg.max_batch_size = int(max_batch_size)
         cfg.confidence_threshold = float(confidence_threshold)
         cfg.iou_threshold = float(iou_threshold)
+        cfg.precision = int(precision)   # 0 = bf16 product path, 1 = PRECISION_F32 parity mode (R50 only)
         cfg.device_id = int(device_id)
         cfg.max_det = int(max_det)
         cfg.backbone = int(backbone)

@@ -32,7 +32,7 @@ def _kernel_notes(obj, tmp):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="LLVM offload tools not installed")
 def test_no_device_kernel_spills_to_scratch(tmp_path):
-    objs = [os.path.join(BUILD, f + ".o") for f in ("kernels_pre", "kernels_post", "kernels_conv")]
+    objs = [os.path.join(BUILD, f + ".o") for f in ("kernels_pre", "kernels_post", "kernels_conv", "kernels_f32")]
     missing = [o for o in objs if not os.path.exists(o)]
     assert not missing, "run rs-face-detection_amd/build.sh (or __graft_entry__.build()) first: %s" % missing
     total = 0
@@ -55,7 +55,7 @@ _needs_llvm = pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-obj
 @pytest.fixture(scope="module")
 def disasm(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("isa"))
-    return {f: isa_check.disassemble(os.path.join(BUILD, f + ".o"), tmp) for f in ("kernels_pre", "kernels_post", "kernels_conv")}
+    return {f: isa_check.disassemble(os.path.join(BUILD, f + ".o"), tmp) for f in ("kernels_pre", "kernels_post", "kernels_conv", "kernels_f32")}
 
 
 @_needs_llvm

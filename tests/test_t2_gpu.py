@@ -47,10 +47,9 @@ def _fg_scores(heads, b):
     return np.concatenate(out)
 
 
-def test_t2_bf16_network_vs_f32_network(rfd, oracle):
-    from rfd_hip import convert
-    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
-    det = rfd.RetinaFaceDetection(max_batch_size=N, max_det=2048, confidence_threshold=THR, iou_threshold=IOU_THR)
+@pytest.fixture(scope="module")
+def t2_setup(oracle):
+    """Calibrated random parameters, the 32 preprocessed frames and the torch-CPU f32 heads of both legs."""
     P = unfolded_ref.make_params(777)
     frames = [helpers.make_image(9000 + i, 640, 640, n_blobs=8) for i in range(N)]
     tensor = np.stack([oracle.preprocess(f, 640, 640)[1] for f in frames])
@@ -73,10 +72,68 @@ def test_t2_bf16_network_vs_f32_network(rfd, oracle):
     for st in (32, 16, 8):
         P["head%d_cls_bias" % st] = P["head%d_cls_bias" % st].copy()
         P["head%d_cls_bias" % st][2:4] += np.float32(delta)
-    convert.import_unfolded(det, g, P)
     with torch.no_grad():
         f32_heads = [unfolded_ref.forward(P, torch.from_numpy(tensor[i:i + 4])) for i in range(0, N, 4)]
     f32_heads = [np.concatenate([c[k] for c in f32_heads], 0) for k in range(9)]
+    return P, frames, tensor, f32_heads, delta
+
+
+def test_t2_f32_parity_mode_vs_f32_network(rfd, oracle, t2_setup):
+    """The exact leg (round 3): the device in its f32 parity mode (rfd_config.precision = RFD_PRECISION_F32: f32 weights,
+    activations and accumulation -- the reference's FP32 tensor contract, face_detection.rs:261-279) against the torch-CPU f32
+    evaluation of the same unfolded parameters.  north_star's bar applies END TO END here: per frame the kept-anchor index
+    sequences are identical and every coordinate agrees within 1e-4 (frames are 640 x 640: det_scale 1, network pixels).
+    A candidate whose f32 score sits within f32 accumulation noise of the threshold or of a competitor may legitimately fall
+    on the other side; such frames are listed with their margins and bounded (none on this seed when the test was written)."""
+    from rfd_hip import convert
+    P, frames, tensor, f32_heads, delta = t2_setup
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    det = rfd.RetinaFaceDetection(max_batch_size=N, max_det=2048, confidence_threshold=THR, iou_threshold=IOU_THR,
+                                  precision=rfd.PRECISION_F32)
+    convert.import_unfolded(det, g, P)
+    dev_heads = det.forward(tensor)
+    rel = [float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())) for a, b in zip(dev_heads, f32_heads)]
+    mx = [float(np.abs(a - b).max()) for a, b in zip(dev_heads, f32_heads)]
+    print("f32 mode: head relative L2", rel, "max abs", mx)
+    assert max(rel) < 2e-5, rel            # f32 accumulation-order noise through ~60 layers (bf16 leg: 3e-3 .. 2e-2)
+    dev_rows = det.decode_nms(dev_heads, np.ones(N, np.float32), want_gidx=True)
+    fused = det.call_batch(frames[:4])     # preprocess + f32 network + decode + NMS in one call gives the same rows
+    for b in range(4):
+        assert np.array_equal(fused[b][0], dev_rows[b][0]) and np.array_equal(fused[b][1], dev_rows[b][1])
+    flips, worst_coord, worst_score, kept = [], 0.0, 0.0, 0
+    for b in range(N):
+        odet, olmk, ogidx, _ = oracle.decode_nms([h[b] for h in f32_heads], 640, 640, np.float32(THR), IOU_THR, 1.0)
+        gdet, glmk, ggidx = dev_rows[b]
+        kept += len(ogidx)
+        if not np.array_equal(ggidx, ogidx):
+            sf = _fg_scores(f32_heads, b)
+            only = sorted(set(ogidx.tolist()) ^ set(ggidx.tolist()))
+            flips.append((b, only, [float(abs(sf[a] - THR)) for a in only]))
+            continue
+        worst_coord = max(worst_coord, float(np.abs(gdet[:, :4] - odet[:, :4]).max(initial=0)), float(np.abs(glmk - olmk).max(initial=0)))
+        worst_score = max(worst_score, float(np.abs(gdet[:, 4] - odet[:, 4]).max(initial=0)))
+    print("f32 mode: kept %d boxes over %d frames; frames with a differing kept set: %s; worst coordinate diff %.3g px, score diff %.3g"
+          % (kept, N, flips, worst_coord, worst_score))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump({"frames": N, "kept_f32_reference": kept, "head_rel_l2": rel, "head_max_abs": mx, "frames_with_differing_kept_set": flips,
+                   "worst_coord_abs_diff_px": worst_coord, "worst_score_abs_diff": worst_score},
+                  open(os.path.join(ROOT, "gpurun_out", "t2_f32_mode_metrics.json"), "w"), indent=1)
+    except OSError:
+        pass
+    det.close()
+    assert kept > 300
+    assert worst_coord <= 1e-4 and worst_score <= 1e-5                 # north_star: coordinates within 1e-4
+    # identical kept-index sets; a frame may differ only through a candidate whose f32 score is within 2e-6 of the threshold
+    assert all(all(m < 2e-6 for m in margins) for _, _, margins in flips) and len(flips) <= 1, flips
+
+
+def test_t2_bf16_network_vs_f32_network(rfd, oracle, t2_setup):
+    from rfd_hip import convert
+    P, frames, tensor, f32_heads, delta = t2_setup
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    det = rfd.RetinaFaceDetection(max_batch_size=N, max_det=2048, confidence_threshold=THR, iou_threshold=IOU_THR)
+    convert.import_unfolded(det, g, P)
     dev_heads = det.forward(tensor)
     scale = np.ones(N, np.float32)
     dev_rows = det.decode_nms(dev_heads, scale, want_gidx=True)

@@ -9,6 +9,6 @@ mkdir -p "$ROOT/tools/bin"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function "$@" \
     -c "${SRC:-$PKG/csrc/kernels_conv.hip}" -o "$ROOT/tools/bin/kernels_conv_$NAME.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/bin/librfd_hip_$NAME.so" "$PKG/build/kernels_pre.o" \
-    "$PKG/build/kernels_post.o" "$ROOT/tools/bin/kernels_conv_$NAME.o" "$PKG/build/network.o" "$PKG/build/detector.o" -ldl
+    "$PKG/build/kernels_post.o" "$ROOT/tools/bin/kernels_conv_$NAME.o" "$PKG/build/kernels_f32.o" "$PKG/build/network.o" "$PKG/build/detector.o" -ldl
 rm -f "$ROOT/tools/bin/kernels_conv_$NAME.o"
 echo "built tools/bin/librfd_hip_$NAME.so"

@@ -228,7 +228,7 @@ def ds_read_b128_under_partial_exec(ins):
     return bad
 
 
-def report(objs=("kernels_pre", "kernels_post", "kernels_conv")):
+def report(objs=("kernels_pre", "kernels_post", "kernels_conv", "kernels_f32")):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         for f in objs:
