@@ -29,6 +29,17 @@ def test_bench_json_contract():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.02 < rf["frac"] < 1.0
+    # traffic: PMC bytes per pass, measured by child rocprofv3 passes of this very run when the profiler is on the box (else the
+    # committed summary, labelled); either way within a sane band of the algorithmic 13 GB of the graph as fused
+    assert "traffic_source" in rf
+    if rf["traffic"] is not None:
+        assert 10e9 < rf["traffic"] < 25e9, rf["traffic"]
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    # the sustained window (>= 3 s of the same step) next to the short timed loop
+    su = d["sustained"]
+    assert su["seconds"] >= 3.0 and su["steps"] >= 10 and su["images_per_s"] > 0.8 * d["value"]
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

@@ -8,7 +8,7 @@ OUT="gpurun_out/ab_${TAG}.jsonl"
 : > "$OUT"
 for spec in "$@"; do
   label="${spec%%|*}"; envs="${spec#*|}"
-  line=$(env $envs RFD_BENCH_HOST_PATH=0 RFD_BENCH_SUSTAIN_S=${SUSTAIN_S:-1.5} python bench.py --no-cpu-baseline --steps ${STEPS:-30} --warmup 5 2>>gpurun_out/ab_${TAG}.err | tail -1)
+  line=$(env $envs RFD_BENCH_HOST_PATH=0 RFD_BENCH_TRAFFIC=off RFD_BENCH_SUSTAIN_S=${SUSTAIN_S:-1.5} python bench.py --no-cpu-baseline --steps ${STEPS:-30} --warmup 5 2>>gpurun_out/ab_${TAG}.err | tail -1)
   echo "{\"label\": \"$label\", \"env\": \"$envs\", \"result\": $line}" >> "$OUT"
   python - "$label" "$line" <<'PY'
 import json, sys

@@ -6,7 +6,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-export RFD_BENCH_HOST_PATH=0
+export RFD_BENCH_HOST_PATH=0 RFD_BENCH_TRAFFIC=off RFD_BENCH_SUSTAIN=0
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_under_rocprof.log 2>&1
