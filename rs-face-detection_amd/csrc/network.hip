@@ -427,6 +427,7 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_, int prec
     RFD_HIP(hipEventCreateWithFlags(&ev_part_fork, hipEventDisableTiming));
     RFD_HIP(hipEventCreateWithFlags(&ev_shift, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) RFD_HIP(hipEventCreateWithFlags(&ev_hyb[i], hipEventDisableTiming));
+
     configure_hybrid();
     if (getenv("RFD_CHAIN_SHIFT")) chain_shift_op = atoi(getenv("RFD_CHAIN_SHIFT"));
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
@@ -476,6 +477,7 @@ void Network::destroy()
     if (ev_shift) (void)hipEventDestroy(ev_shift);
     ev_shift = nullptr;
     for (int i = 0; i < 3; ++i) { if (ev_hyb[i]) (void)hipEventDestroy(ev_hyb[i]); ev_hyb[i] = nullptr; }
+
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (hipGraphExec_t ge : graph_exec)
         if (ge) (void)hipGraphExecDestroy(ge);
@@ -709,11 +711,23 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
     hipStream_t main_stream = s;
     const bool fork_ok = multi_stream && !profiling && ((first_op <= 0 && last_op == nops - 1) || partial_fork) && side[part][0] && side[part][1];
     bool forked[2] = {false, false};
+    // timing-only experiment (results are garbage): RFD_SKIP_OPS="42,45" leaves those ops out of the pass -- the step time without
+    // them bounds what ANY faster kernel for them could buy end to end in the overlapped two-chain pass (tools/ab_bench.sh)
+    static const std::vector<int> skip_ops = [] {
+        std::vector<int> v;
+        if (const char *e = getenv("RFD_SKIP_OPS"))
+            for (const char *q = e; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        return v;
+    }();
     for (int i = std::max(first_op, 0); i <= last_op; ++i) {
         const Op &o = g.ops[i];
         const Layer &L = g.layers[o.layer];
         const TensorDesc &tin = g.tensors[o.in];
         s = main_stream;
+        if (!skip_ops.empty() && std::find(skip_ops.begin(), skip_ops.end(), i) != skip_ops.end()) {
+            if (profiling) { RFD_HIP(hipEventRecord(ev[2 * i], s)); RFD_HIP(hipEventRecord(ev[2 * i + 1], s)); }
+            continue;
+        }
         if (fork_ok && o.branch > 0) {
             const int bidx = o.branch - 1;
             if (!forked[bidx]) { // everything this chain reads was enqueued on the main stream before this point
@@ -905,6 +919,7 @@ int Network::ensure_alt_heads()
         RFD_HIP(hipMalloc(&d_alt[bi], g.buffer_bytes_per_image[bi] * (size_t)max_batch));
         RFD_HIP(hipMemset(d_alt[bi], 0, g.buffer_bytes_per_image[bi] * (size_t)max_batch));
     }
+
     return RFD_OK;
 }
 
@@ -945,9 +960,11 @@ void Network::configure_hybrid()
     hybrid_join = hybrid_resplit = -1;
     const char *e = getenv("RFD_HYBRID");
     const int mode = e ? atoi(e) : 0;
-    if (mode <= 0) return;
+    if (mode <= 0 || g.backbone != RFD_BACKBONE_R50) return;
     hybrid_join = op_from_env(g, "RFD_HYBRID_JOIN", "stage4_unit1_conv1");
-    if (mode >= 2) hybrid_resplit = op_from_env(g, "RFD_HYBRID_RESPLIT", "fpn_lat1");
+    if (mode == 2) hybrid_resplit = op_from_env(g, "RFD_HYBRID_RESPLIT", "fpn_lat1");
+    // (mode 3 of round 3 -- ops [join, end) of call i on a third stream under the chains of call i+1, every workspace buffer
+    //  doubled -- measured 7 249 / 7 275 against 7 301 / 7 405 img/s and was removed: profiles/r03_ab_pipelined_hybrid.jsonl)
     const int nops = (int)g.ops.size();
     if (hybrid_join <= 0 || hybrid_join >= nops) hybrid_join = hybrid_resplit = -1;
     if (hybrid_resplit >= 0 && (hybrid_resplit <= hybrid_join || hybrid_resplit >= nops)) hybrid_resplit = -1;
