@@ -454,6 +454,10 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_resync, 0));
     }
     c->ov_last_n = n;
+    // (Round 3 also ran each call as ONE whole-batch chain on the stream of its parity, the next call beside it in a second copy of
+    //  the workspace: bit-exact, and no faster than the half-batch chains -- 7 721 / 7 432 / 7 474 / 7 534 against 7 439 / 7 642 /
+    //  7 486 / 7 421 img/s, profiles/r03_ab_whole_call_chains.jsonl: at 32 images nearly every kernel fills the chip, so the two
+    //  chains simply alternate.  Removed.)
     if (c->ov_post_valid[par])
         for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_post_done[par], 0));
     RFD_HIP(hipMemcpyAsync(c->ov_imgs[par].p, pis, n * sizeof(PreImage), hipMemcpyHostToDevice, st[0]));
@@ -476,13 +480,8 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
         status = launch_preprocess(pp, Bp, st[p]);
         if (status == RFD_OK && p == 1 && net.chain_shift_op >= 0 && net.chain_shift_op < (int)net.g.ops.size() &&
             hipStreamWaitEvent(st[1], net.ev_shift, 0) != hipSuccess) status = RFD_ERR_HIP;
-        if (status == RFD_OK) status = net.run(Bp, st[p], 0, net.hybrid_join > 0 ? net.hybrid_join - 1 : -1, off, p);
-        if (status == RFD_OK && net.hybrid_join <= 0 && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
-    }
-    if (status == RFD_OK && net.hybrid_join > 0) { // hybrid split: the small-M range runs once over the whole batch (Network::hybrid_tail)
-        status = net.hybrid_tail(n, B0, st[0], st[1]);
-        for (int p = 0; p < 2 && status == RFD_OK; ++p)
-            if (hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
+        if (status == RFD_OK) status = net.run(Bp, st[p], 0, -1, off, p);
+        if (status == RFD_OK && hipEventRecord(c->ov_chain_done[par][p], st[p]) != hipSuccess) status = RFD_ERR_HIP;
     }
     net.co_running = 0;
     if (status != RFD_OK) { net.head_parity = 0; c->ov_last_n = -1; return status; }

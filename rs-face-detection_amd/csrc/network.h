@@ -160,16 +160,7 @@ struct Network {
     // memory-bound) but stay a few ops apart; -1 = both start together
     int chain_shift_op = -1;
     hipEvent_t ev_shift = nullptr;
-    // Hybrid split (round 3): the small-M layers (stage 4 at 20x20 and the stride-32 / stride-16 pyramid levels) cost a 32-image
-    // launch about as much as a 16-image one, so the two chains JOIN before op hybrid_join (both parts' ops [0, join) done), ops
-    // [join, resplit) run ONCE over the whole batch on chain 0's stream (+ its side streams), and -- hybrid_resplit > 0 -- the
-    // stride-8 tail [resplit, end) is split over the two chains again.  -1 = off (two independent chains to the end).
-    int hybrid_join = -1, hybrid_resplit = -1;
-    bool partial_fork = false; // run(): side-stream forks allowed in a partial op range (set by the hybrid phases)
-    hipEvent_t ev_hyb[3] = {};
-    void configure_hybrid();   // from RFD_HYBRID / RFD_HYBRID_JOIN / RFD_HYBRID_RESPLIT (op names or indices)
-    // phases after the two chains have enqueued ops [0, hybrid_join) of their parts on st[0] / st[1]
-    int hybrid_tail(int B, int B0, hipStream_t st0, hipStream_t st1);
+    bool partial_fork = false; // run(): side-stream forks allowed in a partial op range too
     int co_running = 0;      // set while the parts of a split pass are being enqueued
     int split_min_part = 4;  // fewest images a part may hold (B = 8: 4.02 k img/s split vs 3.86 k as one graph; B <= 6: graph wins or ties)
     int split_max_parts = 2; // parts = clamp(B / split_min_part, 1, split_max_parts)

@@ -426,9 +426,7 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_, int prec
     }
     RFD_HIP(hipEventCreateWithFlags(&ev_part_fork, hipEventDisableTiming));
     RFD_HIP(hipEventCreateWithFlags(&ev_shift, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) RFD_HIP(hipEventCreateWithFlags(&ev_hyb[i], hipEventDisableTiming));
 
-    configure_hybrid();
     if (getenv("RFD_CHAIN_SHIFT")) chain_shift_op = atoi(getenv("RFD_CHAIN_SHIFT"));
     RFD_HIP(hipMalloc((void **)&d_zero, 256));
     RFD_HIP(hipMemset(d_zero, 0, 256));
@@ -476,7 +474,7 @@ void Network::destroy()
     ev_part_fork = nullptr;
     if (ev_shift) (void)hipEventDestroy(ev_shift);
     ev_shift = nullptr;
-    for (int i = 0; i < 3; ++i) { if (ev_hyb[i]) (void)hipEventDestroy(ev_hyb[i]); ev_hyb[i] = nullptr; }
+
 
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (hipGraphExec_t ge : graph_exec)
@@ -919,7 +917,6 @@ int Network::ensure_alt_heads()
         RFD_HIP(hipMalloc(&d_alt[bi], g.buffer_bytes_per_image[bi] * (size_t)max_batch));
         RFD_HIP(hipMemset(d_alt[bi], 0, g.buffer_bytes_per_image[bi] * (size_t)max_batch));
     }
-
     return RFD_OK;
 }
 
@@ -943,75 +940,20 @@ void Network::assign_streams(int a, int b, int c)
     }
 }
 
-// op index from an environment value: a number, or the name of the op's layer
-static int op_from_env(const Graph &g, const char *name, const char *dflt)
-{
-    const char *e = getenv(name);
-    if (!e || !*e) e = dflt;
-    if (!e) return -1;
-    if (*e == '-' || (*e >= '0' && *e <= '9')) return atoi(e);
-    for (size_t i = 0; i < g.ops.size(); ++i)
-        if (g.ops[i].layer >= 0 && g.layers[g.ops[i].layer].name == e) return (int)i;
-    return -1;
-}
-
-void Network::configure_hybrid()
-{
-    hybrid_join = hybrid_resplit = -1;
-    const char *e = getenv("RFD_HYBRID");
-    const int mode = e ? atoi(e) : 0;
-    if (mode <= 0 || g.backbone != RFD_BACKBONE_R50) return;
-    hybrid_join = op_from_env(g, "RFD_HYBRID_JOIN", "stage4_unit1_conv1");
-    if (mode == 2) hybrid_resplit = op_from_env(g, "RFD_HYBRID_RESPLIT", "fpn_lat1");
-    // (mode 3 of round 3 -- ops [join, end) of call i on a third stream under the chains of call i+1, every workspace buffer
-    //  doubled -- measured 7 249 / 7 275 against 7 301 / 7 405 img/s and was removed: profiles/r03_ab_pipelined_hybrid.jsonl)
-    const int nops = (int)g.ops.size();
-    if (hybrid_join <= 0 || hybrid_join >= nops) hybrid_join = hybrid_resplit = -1;
-    if (hybrid_resplit >= 0 && (hybrid_resplit <= hybrid_join || hybrid_resplit >= nops)) hybrid_resplit = -1;
-    // a side chain forked inside [join, resplit) is joined at the end of that range (run() joins what it forked), so the range
-    // boundaries may sit anywhere on the main chain
-    if (getenv("RFD_STREAM_TUNE_VERBOSE")) fprintf(stderr, "[rfd] hybrid split: join before op %d, re-split before op %d\n", hybrid_join, hybrid_resplit);
-}
-
-int Network::hybrid_tail(int B, int B0, hipStream_t st0, hipStream_t st1)
-{
-    // join: chain 0's stream continues behind chain 1's ops [0, join)
-    RFD_HIP(hipEventRecord(ev_hyb[0], st1));
-    RFD_HIP(hipStreamWaitEvent(st0, ev_hyb[0], 0));
-    const int last_joined = hybrid_resplit > 0 ? hybrid_resplit - 1 : -1;
-    partial_fork = true;
-    co_running = hybrid_resplit > 0 ? 1 : 0; // kernel choice inside the joined range: nothing runs beside it except its own side chains
-    int st = run(B, st0, hybrid_join, last_joined, 0, 0);
-    co_running = 1;
-    if (st == RFD_OK && hipEventRecord(ev_hyb[1], st0) != hipSuccess) st = RFD_ERR_HIP;
-    // chain 1's stream resumes (re-split) or simply orders itself behind the joined range: its workspace slice is in use until then
-    if (st == RFD_OK && hipStreamWaitEvent(st1, ev_hyb[1], 0) != hipSuccess) st = RFD_ERR_HIP;
-    if (st == RFD_OK && hybrid_resplit > 0) {
-        st = run(B0, st0, hybrid_resplit, -1, 0, 0);
-        if (st == RFD_OK) st = run(B - B0, st1, hybrid_resplit, -1, B0, 1);
-    }
-    partial_fork = false;
-    return st;
-}
+// Round 3 tried a HYBRID split on the verdict's suggestion -- two 16-image chains up to stage 4, then stage 4 + the stride-32 /
+// stride-16 pyramid levels ONCE over the whole batch (their launches cost a 32-image batch about what they cost 16 images),
+// optionally re-split for the stride-8 tail, or pipelined on a third stream under the next call's chains with the workspace
+// doubled.  All three forms measured SLOWER than two independent chains (7 445 / 7 278, 7 422 / 7 395, 7 249 / 7 275 against
+// 7 643 / 7 499 / 7 301 / 7 405 img/s on the same boxes: profiles/r03_ab_safe_waits_hybrid.jsonl, r03_ab_pipelined_hybrid.jsonl):
+// stage 4's kernels occupy 100-200 CUs and the other chain already fills the rest, so joining only removes overlap.  The
+// joined range also picks kernels by its own batch size, which for two layers means another f32 summation order, i.e. heads
+// that differ in the last bf16 bit from the split pass (tests/test_concurrency_gpu.py fails with it).  Removed.
 
 int Network::split_body(int B, int P, hipStream_t s)
 {
     RFD_HIP(hipEventRecord(ev_part_fork, s));
     co_running = 1;
     int off = 0, st = RFD_OK;
-    if (P == 2 && hybrid_join > 0) { // hybrid: two chains up to the join, the small-M range once over the whole batch
-        const int B0 = B / 2 + (B % 2);
-        for (int p = 0; p < 2 && st == RFD_OK; ++p) {
-            RFD_HIP(hipStreamWaitEvent(part_stream[p], ev_part_fork, 0));
-            st = run(p ? B - B0 : B0, part_stream[p], 0, hybrid_join - 1, p ? B0 : 0, p);
-        }
-        if (st == RFD_OK) st = hybrid_tail(B, B0, part_stream[0], part_stream[1]);
-        for (int p = 0; p < 2 && st == RFD_OK; ++p) RFD_HIP(hipEventRecord(ev_part_join[p], part_stream[p]));
-        co_running = 0;
-        RFD_TRY(st);
-        for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(s, ev_part_join[p], 0));
-        return RFD_OK;
-    }
     for (int p = 0; p < P && st == RFD_OK; ++p) {
         const int Bp = B / P + (p < B % P ? 1 : 0);
         RFD_HIP(hipStreamWaitEvent(part_stream[p], ev_part_fork, 0));
