@@ -201,12 +201,13 @@ struct rfd_ctx {
         float *pin_scale = nullptr;
         float *h_ob = nullptr, *h_ol = nullptr;
         int *h_oc = nullptr, *h_ot = nullptr;
-        hipEvent_t h2d = nullptr, done = nullptr;
+        hipEvent_t h2d = nullptr, done = nullptr, post = nullptr;
         int n = 0;
     };
     static constexpr int kPipe = 2;
+    static constexpr int kPipeRows = 128; // rows per image the pipelined entry copies back unconditionally
     PipeSlot pipe[kPipe];
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
     int pipe_head = 0, pipe_tail = 0, pipe_inflight = 0;
     // cross-call overlap (rfd_detect_batch_device, async = 2): per-parity descriptors and events
     DevBuf ov_imgs[2], ov_scale[2];
@@ -416,7 +417,7 @@ int finish_stats(rfd_ctx *c, int n, bool have_pre, bool have_net)
 //                                          post-processing of call i (ov_post_done) before it touches that parity again
 //   workspace slices, network input       : private to a part, protected by the part stream's order
 //   output slabs (caller's)               : written by NMS on the caller's stream, i.e. in the caller's own order
-int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
+int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out, hipEvent_t frames_ready = nullptr)
 {
     Network &net = c->net;
     RFD_TRY(net.ensure_alt_heads());
@@ -458,6 +459,8 @@ int detect_overlapped(rfd_ctx *c, const rfd_image *imgs, int n, rfd_dets *out)
     //  the workspace: bit-exact, and no faster than the half-batch chains -- 7 721 / 7 432 / 7 474 / 7 534 against 7 439 / 7 642 /
     //  7 486 / 7 421 img/s, profiles/r03_ab_whole_call_chains.jsonl: at 32 images nearly every kernel fills the chip, so the two
     //  chains simply alternate.  Removed.)
+    if (frames_ready) // pipelined host entry: the frames of this call are still crossing PCIe on the copy stream
+        for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], frames_ready, 0));
     if (c->ov_post_valid[par])
         for (int p = 0; p < 2; ++p) RFD_HIP(hipStreamWaitEvent(st[p], c->ov_post_done[par], 0));
     RFD_HIP(hipMemcpyAsync(c->ov_imgs[par].p, pis, n * sizeof(PreImage), hipMemcpyHostToDevice, st[0]));
@@ -666,6 +669,7 @@ void rfd_destroy(rfd_ctx *c)
             if (h) (void)hipHostFree(h);
         if (ps.h2d) (void)hipEventDestroy(ps.h2d);
         if (ps.done) (void)hipEventDestroy(ps.done);
+        if (ps.post) (void)hipEventDestroy(ps.post);
     }
     for (int a = 0; a < 2; ++a) {
         c->ov_imgs[a].release(); c->ov_scale[a].release();
@@ -676,6 +680,7 @@ void rfd_destroy(rfd_ctx *c)
     if (c->ov_desc) (void)hipEventDestroy(c->ov_desc);
     if (c->ov_resync) (void)hipEventDestroy(c->ov_resync);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1105,7 +1110,6 @@ int rfd_submit_batch(rfd_ctx *c, const rfd_image *imgs, int n)
     }
     RFD_HIP(hipSetDevice(c->cfg.device_id));
     RFD_TRY(c->ensure_network());
-    c->ov_last_n = -1;
     const size_t B = (size_t)c->cfg.max_batch_size, MD = (size_t)c->cfg.max_det;
     rfd_ctx::PipeSlot &ps = c->pipe[c->pipe_head];
     if (!c->copy_stream) RFD_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -1138,36 +1142,76 @@ int rfd_submit_batch(rfd_ctx *c, const rfd_image *imgs, int n)
             set_error("invalid argument: frame %d (%dx%d) letterboxes to an empty image", i, imgs[i].width, imgs[i].height);
             return RFD_ERR_INVALID_ARG;
         }
-        uint8_t *dst = (uint8_t *)ps.frames.p + off;
-        const size_t row = (size_t)imgs[i].width * 3;
-        RFD_HIP(hipMemcpy2DAsync(dst, row, imgs[i].data, (size_t)imgs[i].stride, row, imgs[i].height, hipMemcpyHostToDevice,
-                                 c->copy_stream));
-        ps.pin_imgs[i].src = dst;
-        ps.pin_imgs[i].stride = (long long)row;
-        off += row * imgs[i].height;
+        ps.pin_imgs[i].src = (uint8_t *)ps.frames.p + off;
+        ps.pin_imgs[i].stride = (long long)imgs[i].width * 3;
+        off += (size_t)imgs[i].width * 3 * imgs[i].height;
+    }
+    // Frames that lie back to back in host memory with tight rows (a decoder writing into one rfd_host_alloc block) travel as
+    // ONE copy per run: every copy command on the copy stream costs the compute streams a little (the same 39 MB as 32 commands
+    // measured 0.1 ms per batch slower than as one, round 3).
+    for (int i = 0; i < n;) {
+        size_t bytes = (size_t)imgs[i].width * 3 * imgs[i].height;
+        int j = i + 1;
+        if (imgs[i].stride == (ptrdiff_t)imgs[i].width * 3) {
+            while (j < n && imgs[j].stride == (ptrdiff_t)imgs[j].width * 3 && imgs[j].data == imgs[i].data + bytes) {
+                bytes += (size_t)imgs[j].width * 3 * imgs[j].height;
+                ++j;
+            }
+            RFD_HIP(hipMemcpyAsync((void *)ps.pin_imgs[i].src, imgs[i].data, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        } else {
+            const size_t row = (size_t)imgs[i].width * 3;
+            RFD_HIP(hipMemcpy2DAsync((void *)ps.pin_imgs[i].src, row, imgs[i].data, (size_t)imgs[i].stride, row, imgs[i].height,
+                                     hipMemcpyHostToDevice, c->copy_stream));
+        }
+        i = j;
     }
     RFD_HIP(hipMemcpyAsync(ps.imgs.p, ps.pin_imgs, n * sizeof(PreImage), hipMemcpyHostToDevice, c->copy_stream));
     RFD_HIP(hipMemcpyAsync(ps.scale.p, ps.pin_scale, n * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
     RFD_HIP(hipEventRecord(ps.h2d, c->copy_stream));
-    // main stream: the whole hot path of this batch, behind the previous batch
-    RFD_HIP(hipStreamWaitEvent(c->stream, ps.h2d, 0));
-    PreParams pp;
-    memset(&pp, 0, sizeof pp);
-    pp.imgs = (const PreImage *)ps.imgs.p;
-    pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
-    pp.out_nhwc4 = (bf16_t *)c->net.tensor_ptr(c->net.g.input);
-    RFD_TRY(launch_preprocess(pp, n, c->stream));
-    RFD_TRY(c->net.run_graphed(n, c->stream));
-    DecodeParams dp;
-    fill_decode_params(c, dp);
-    for (int l = 0; l < kNumLevels; ++l) dp.cls[l] = (const float *)c->net.tensor_ptr(c->net.g.heads[l]);
-    RFD_TRY(post_network(c, dp, false, n, (float *)ps.ob.p, (float *)ps.ol.p, (int *)ps.oc.p, (int *)ps.ot.p, nullptr,
-                         (const float *)ps.scale.p));
-    RFD_HIP(hipMemcpyAsync(ps.h_ob, ps.ob.p, n * MD * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    RFD_HIP(hipMemcpyAsync(ps.h_ol, ps.ol.p, n * MD * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    RFD_HIP(hipMemcpyAsync(ps.h_oc, ps.oc.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    RFD_HIP(hipMemcpyAsync(ps.h_ot, ps.ot.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    RFD_HIP(hipEventRecord(ps.done, c->stream));
+    if (!c->net.profiling && c->net.multi_stream && c->net.num_parts(n) == 2 && c->net.weights_ready) {
+        // Round 3: the same two-chain, cross-call-overlapped pass rfd_detect_batch_device(async = 2) runs -- the chains of this
+        // batch wait for its frames (h2d) and otherwise only for their own stream order, so they start under the tail and the
+        // decode / sort / NMS of the previous batch.  (Until round 2 the whole pass sat on the caller's stream behind the previous
+        // batch, D2H included: 7.0 k against 7.5 k img/s device-resident.)
+        std::vector<rfd_image> dev(n);
+        for (int i = 0; i < n; ++i) {
+            dev[i].data = (const uint8_t *)ps.pin_imgs[i].src; dev[i].height = imgs[i].height; dev[i].width = imgs[i].width;
+            dev[i].stride = (ptrdiff_t)imgs[i].width * 3;
+        }
+        rfd_dets dd;
+        dd.boxes = (float *)ps.ob.p; dd.landmarks = (float *)ps.ol.p; dd.count = (int *)ps.oc.p; dd.total = (int *)ps.ot.p;
+        RFD_TRY(detect_overlapped(c, dev.data(), n, &dd, ps.h2d));
+    } else {
+        // main stream: the whole hot path of this batch, behind the previous batch
+        c->ov_last_n = -1;
+        RFD_HIP(hipStreamWaitEvent(c->stream, ps.h2d, 0));
+        PreParams pp;
+        memset(&pp, 0, sizeof pp);
+        pp.imgs = (const PreImage *)ps.imgs.p;
+        pp.net_h = c->cfg.image_h; pp.net_w = c->cfg.image_w;
+        pp.out_nhwc4 = (bf16_t *)c->net.tensor_ptr(c->net.g.input);
+        RFD_TRY(launch_preprocess(pp, n, c->stream));
+        RFD_TRY(c->net.run_graphed(n, c->stream));
+        DecodeParams dp;
+        fill_decode_params(c, dp);
+        for (int l = 0; l < kNumLevels; ++l) dp.cls[l] = (const float *)c->net.tensor_ptr(c->net.g.heads[l]);
+        RFD_TRY(post_network(c, dp, false, n, (float *)ps.ob.p, (float *)ps.ol.p, (int *)ps.oc.p, (int *)ps.ot.p, nullptr,
+                             (const float *)ps.scale.p));
+    }
+    // detections go back on their own stream: neither the next batch's compute (caller's stream) nor its frames (copy stream,
+    // enqueued earlier than this batch's NMS finishes) queue behind them
+    if (!c->d2h_stream) RFD_HIP(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    if (!ps.post) RFD_HIP(hipEventCreateWithFlags(&ps.post, hipEventDisableTiming));
+    RFD_HIP(hipEventRecord(ps.post, c->stream));
+    RFD_HIP(hipStreamWaitEvent(c->d2h_stream, ps.post, 0));
+    // the first kPipeRows rows of every image now (two strided copies); an image that kept more has the rest fetched by
+    // rfd_collect_batch -- dense crowds only: the slabs hold max_det rows per image, a typical frame uses a few dozen
+    const size_t R = std::min<size_t>(MD, rfd_ctx::kPipeRows);
+    RFD_HIP(hipMemcpy2DAsync(ps.h_ob, MD * 5 * sizeof(float), ps.ob.p, MD * 5 * sizeof(float), R * 5 * sizeof(float), n, hipMemcpyDeviceToHost, c->d2h_stream));
+    RFD_HIP(hipMemcpy2DAsync(ps.h_ol, MD * 10 * sizeof(float), ps.ol.p, MD * 10 * sizeof(float), R * 10 * sizeof(float), n, hipMemcpyDeviceToHost, c->d2h_stream));
+    RFD_HIP(hipMemcpyAsync(ps.h_oc, ps.oc.p, n * sizeof(int), hipMemcpyDeviceToHost, c->d2h_stream));
+    RFD_HIP(hipMemcpyAsync(ps.h_ot, ps.ot.p, n * sizeof(int), hipMemcpyDeviceToHost, c->d2h_stream));
+    RFD_HIP(hipEventRecord(ps.done, c->d2h_stream));
     ps.n = n;
     c->pipe_head = (c->pipe_head + 1) % rfd_ctx::kPipe;
     ++c->pipe_inflight;
@@ -1186,6 +1230,15 @@ int rfd_collect_batch(rfd_ctx *c, rfd_dets *out, int *n_out)
         return check_nms_flag(c);
     }
     const size_t MD = (size_t)c->cfg.max_det;
+    bool more = false;
+    for (int i = 0; i < ps.n; ++i)
+        if ((size_t)ps.h_oc[i] > (size_t)rfd_ctx::kPipeRows) { // rows beyond the prefix copied by rfd_submit_batch
+            const size_t R = rfd_ctx::kPipeRows, k = (size_t)ps.h_oc[i];
+            RFD_HIP(hipMemcpyAsync(ps.h_ob + ((size_t)i * MD + R) * 5, (const float *)ps.ob.p + ((size_t)i * MD + R) * 5, (k - R) * 5 * sizeof(float), hipMemcpyDeviceToHost, c->d2h_stream));
+            RFD_HIP(hipMemcpyAsync(ps.h_ol + ((size_t)i * MD + R) * 10, (const float *)ps.ol.p + ((size_t)i * MD + R) * 10, (k - R) * 10 * sizeof(float), hipMemcpyDeviceToHost, c->d2h_stream));
+            more = true;
+        }
+    if (more) RFD_HIP(hipStreamSynchronize(c->d2h_stream));
     for (int i = 0; i < ps.n; ++i) {
         const int k = ps.h_oc[i];
         memcpy(out->boxes + (size_t)i * MD * 5, ps.h_ob + (size_t)i * MD * 5, (size_t)k * 5 * sizeof(float));

@@ -100,3 +100,25 @@ def test_pipeline_state_errors(rfd):
     a, b = det.collect(), det.collect()
     assert _same(a, b)
     det.close()
+
+
+def test_pipelined_many_detections_and_contiguous_frames(rfd):
+    """Round 3's transfer paths: (i) images that keep more rows than the prefix rfd_submit_batch copies back unconditionally (128)
+    have the rest fetched by rfd_collect_batch; (ii) frames lying back to back in one page-locked block travel as one copy.
+    Both must give exactly the synchronous result."""
+    n = 8
+    det = rfd.RetinaFaceDetection(max_batch_size=n, max_det=2048, confidence_threshold=0.02, iou_threshold=0.9)
+    det.init_synthetic_weights(1234)
+    block = det.host_frames(n, 480, 640)            # one rfd_host_alloc block: frames contiguous, rows tight
+    for i in range(n):
+        block[i] = helpers.make_image(8100 + i, 480, 640, n_blobs=6)
+    frames = [block[i] for i in range(n)]
+    want = det.call_batch(frames)
+    ks = [len(d) for d, _ in want]
+    assert max(ks) > 128 and min(ks) >= 0, ks        # the low threshold / high IoU threshold keep hundreds of boxes
+    det.submit(frames)
+    det.submit(frames[:5])                           # a ragged second batch in flight
+    got = det.collect()
+    got2 = det.collect()
+    assert _same(got, want) and _same(got2, want[:5])
+    det.close()
