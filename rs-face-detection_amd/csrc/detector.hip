@@ -249,6 +249,7 @@ int ctx_alloc(rfd_ctx *c)
     RFD_TRY(c->nms_kept.reserve(B * NA * sizeof(float4)));
     RFD_TRY(c->nms_state.reserve((B * kNmsChunks * 2 + 1) * sizeof(int)));
     RFD_HIP(hipMemset(c->nms_state.p, 0, (B * kNmsChunks * 2 + 1) * sizeof(int)));
+    RFD_HIP(hipDeviceSynchronize()); // the fill runs on the NULL stream, which the context's non-blocking stream is not ordered with
     RFD_TRY(c->count.reserve(B * sizeof(int)));
     RFD_TRY(c->det_scale.reserve(B * sizeof(float)));
     RFD_TRY(c->out_boxes.reserve(B * MD * 5 * sizeof(float)));

@@ -436,6 +436,10 @@ int Network::create(int backbone, int net_w, int net_h, int max_batch_, int prec
         RFD_HIP(hipMalloc(&d_buffers[i], g.buffer_bytes_per_image[i] * (size_t)max_batch));
         RFD_HIP(hipMemset(d_buffers[i], 0, g.buffer_bytes_per_image[i] * (size_t)max_batch));
     }
+    // hipMemset on device memory returns before the fill has run, and it runs on the NULL stream, which the non-blocking streams
+    // everything else uses are not ordered with: without this the fill of d_w could land AFTER the first set_layer() copies and
+    // zero layer 0's weights (round 3: one fresh context in ~16 returned no detections; tests/test_pipeline_gpu.py caught it).
+    RFD_HIP(hipDeviceSynchronize());
     return RFD_OK;
 }
 
@@ -917,6 +921,7 @@ int Network::ensure_alt_heads()
         RFD_HIP(hipMalloc(&d_alt[bi], g.buffer_bytes_per_image[bi] * (size_t)max_batch));
         RFD_HIP(hipMemset(d_alt[bi], 0, g.buffer_bytes_per_image[bi] * (size_t)max_batch));
     }
+    RFD_HIP(hipDeviceSynchronize()); // the fills run on the NULL stream (see Network::create)
     return RFD_OK;
 }
 

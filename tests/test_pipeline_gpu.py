@@ -25,7 +25,17 @@ def test_pipelined_equals_synchronous(rfd, pinned):
                   for i in range(n if b != 3 else 2)]          # a ragged batch in the middle
         batches.append(frames)
     want = [det.call_batch(f) for f in batches]
-    assert sum(len(d) for w in want for d, _ in w) > 0
+    if sum(len(d) for w in want for d, _ in w) == 0:   # diagnostics for an intermittent failure seen twice in round 3
+        g = rfd.Graph(rfd.BACKBONE_MNET025)
+        w0, b0 = det.get_layer(0, g.layers[0])
+        wl, bl = det.get_layer(len(g.layers) - 1, g.layers[-1])
+        di, tn, sc = det.preprocess(batches[0])
+        h = det.forward(tn)
+        again = [det.call_batch(f) for f in batches]
+        raise AssertionError("no detections: stats %s; |w0| %.4g |w_last| %.4g; input sum %.6g scales %s; head |mean| %s max fg %s; second try %s"
+                             % (det.stats(), float(np.abs(w0).mean()), float(np.abs(wl).mean()), float(tn.sum()), sc,
+                                [float(np.abs(x).mean()) for x in h[:9:3]], [float(x[:, 2:4].max()) for x in h[:9:3]],
+                                [sum(len(d) for d, _ in w) for w in again]))
     if pinned:   # same frames, living in page-locked memory handed out by the library
         pin = []
         for frames in batches:
