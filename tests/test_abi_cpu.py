@@ -107,3 +107,21 @@ def test_no_device_no_fallback(rfd):
     boxes = (ctypes.c_float * 20)()
     L._nms(keep, ctypes.byref(num), boxes, 4, 5, 0.4, 0)
     assert num.value == -1
+
+
+def test_config_layout_and_precision_validation(rfd):
+    """rfd_config keeps its round-1 size (the `precision` field took the first reserved word) and rfd_create validates it before
+    it looks for a device, so the check runs here without a GPU."""
+    cfg = rfd.rfd_config()
+    assert ctypes.sizeof(cfg) == 16 * 4
+    assert rfd.rfd_config.precision.offset == 10 * 4 and rfd.rfd_config.backbone.offset == 9 * 4
+    L = rfd.load_library()
+    L.rfd_config_default(ctypes.byref(cfg))
+    assert cfg.precision == rfd.PRECISION_BF16 and cfg.image_w == 640 and cfg.max_det == 1024
+    ctx = ctypes.c_void_p()
+    cfg.precision = 7
+    assert L.rfd_create(ctypes.byref(cfg), ctypes.byref(ctx)) == rfd.RFD_ERR_INVALID_ARG
+    cfg.precision = rfd.PRECISION_F32
+    cfg.backbone = rfd.BACKBONE_MNET025
+    assert L.rfd_create(ctypes.byref(cfg), ctypes.byref(ctx)) == rfd.RFD_ERR_INVALID_ARG
+    assert b"R50" in L.rfd_last_error()

@@ -10,14 +10,18 @@ import torch
 import torch.nn.functional as F
 
 
+_ROUND = [True]  # TorchRef(round_bf16=False) evaluates the same op list WITHOUT the bf16 roundings: the f32 parity mode's reference
+
+
 def bf16r(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(torch.bfloat16).to(torch.float32) if _ROUND[0] else t
 
 
 class TorchRef:
-    def __init__(self, graph, det):
+    def __init__(self, graph, det, round_bf16=True):
         """graph: rfd_hip.Graph; det: rfd_hip.RetinaFaceDetection with initialised weights."""
         self.g = graph
+        self.round_bf16 = round_bf16
         self.w, self.b, self.aff = [], [], []
         for i, L in enumerate(graph.layers):
             w, b = det.get_layer(i, L)
@@ -109,9 +113,13 @@ class TorchRef:
         """x: [n,4,H,W] f32 (R,G,B,0).  Returns dict of all tensors (NCHW f32)."""
         tensors = {next(i for i, t in enumerate(self.g.tensors) if t.is_input): x_nchw4}
         last = len(self.g.ops) - 1 if upto is None else upto
-        with torch.no_grad():
-            for i in range(last + 1):
-                self.run_op(i, tensors)
+        _ROUND[0] = self.round_bf16
+        try:
+            with torch.no_grad():
+                for i in range(last + 1):
+                    self.run_op(i, tensors)
+        finally:
+            _ROUND[0] = True
         return tensors
 
     def heads(self, tensors):
