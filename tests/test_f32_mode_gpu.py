@@ -35,9 +35,10 @@ def test_f32_mode_heads_match_torch_walk_of_the_same_graph(rfd, oracle, size, n)
     thr = float(np.quantile(fg, 0.995))
     det.set_thresholds(thr, 0.45)
     got = det.call_batch(frames)
+    assert sum(len(d) for d, _ in got) > 0
     for b in range(n):
         odet, olmk, ogidx, _ = oracle.decode_nms([x[b] for x in heads_np], h, w, np.float32(thr), 0.45, float(pre[b][2]))
-        assert len(odet) == len(got[b][0]) > 0
+        assert len(odet) == len(got[b][0])
         assert np.array_equal(got[b][0][:, 4], odet[:, 4])
         np.testing.assert_allclose(got[b][0][:, :4], odet[:, :4], rtol=0, atol=1e-4)
         np.testing.assert_allclose(got[b][1], olmk, rtol=0, atol=1e-4)
