@@ -720,6 +720,7 @@ int rfd_set_profiling(rfd_ctx *c, int enable)
 {
     RFD_CHECK_ARG(c, "ctx is null");
     RFD_TRY(c->ensure_network());
+    if (enable && c->net.precision != 0) { set_error("per-op profiling is not available in the f32 parity mode"); return RFD_ERR_STATE; }
     c->net.profiling = enable != 0;
     return RFD_OK;
 }

@@ -160,7 +160,6 @@ struct Network {
     // memory-bound) but stay a few ops apart; -1 = both start together
     int chain_shift_op = -1;
     hipEvent_t ev_shift = nullptr;
-    bool partial_fork = false; // run(): side-stream forks allowed in a partial op range too
     int co_running = 0;      // set while the parts of a split pass are being enqueued
     int split_min_part = 4;  // fewest images a part may hold (B = 8: 4.02 k img/s split vs 3.86 k as one graph; B <= 6: graph wins or ties)
     int split_max_parts = 2; // parts = clamp(B / split_min_part, 1, split_max_parts)

@@ -711,7 +711,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
     if (last_op < 0 || last_op >= nops) last_op = nops - 1;
     if (part == 0) { prof_first = std::max(first_op, 0); prof_last = last_op; }
     hipStream_t main_stream = s;
-    const bool fork_ok = multi_stream && !profiling && ((first_op <= 0 && last_op == nops - 1) || partial_fork) && side[part][0] && side[part][1];
+    const bool fork_ok = multi_stream && !profiling && first_op <= 0 && last_op == nops - 1 && side[part][0] && side[part][1];
     bool forked[2] = {false, false};
     // timing-only experiment (results are garbage): RFD_SKIP_OPS="42,45" leaves those ops out of the pass -- the step time without
     // them bounds what ANY faster kernel for them could buy end to end in the overlapped two-chain pass (tools/ab_bench.sh)

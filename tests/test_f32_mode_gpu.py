@@ -52,3 +52,26 @@ def test_f32_mode_is_r50_only_and_validated(rfd):
     with pytest.raises(rfd.RfdError) as e:
         rfd.RetinaFaceDetection(precision=7)
     assert e.value.status == rfd.RFD_ERR_INVALID_ARG
+
+
+def test_f32_mode_weight_file_round_trip_and_guards(rfd, tmp_path):
+    """RFDW save / load carries the unrounded f32 values in this mode; hooks that assume the bf16 layout say so."""
+    det = rfd.RetinaFaceDetection(image_size=(320, 256), max_batch_size=1, precision=rfd.PRECISION_F32)
+    det.init_synthetic_weights(99)
+    frames = [helpers.make_image(31, 256, 320, n_blobs=4)]
+    _, tn, _ = det.preprocess(frames)
+    h0 = det.forward(tn)
+    path = str(tmp_path / "w.rfdw")
+    det.save_weights(path)
+    det2 = rfd.RetinaFaceDetection(image_size=(320, 256), max_batch_size=1, precision=rfd.PRECISION_F32)
+    det2.load_weights(path)
+    h1 = det2.forward(tn)
+    for a, b in zip(h0, h1):
+        assert np.array_equal(a, b)
+    g = rfd.Graph(rfd.BACKBONE_R50, 320, 256)
+    w, _ = det.get_layer(5, g.layers[5])
+    assert np.any(helpers.bf16_round(w) != w)          # unrounded values, not the bf16 copy
+    with pytest.raises(rfd.RfdError) as e:
+        det.set_profiling(True)
+    assert e.value.status == rfd.RFD_ERR_STATE
+    det.close(); det2.close()
