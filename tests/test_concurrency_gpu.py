@@ -145,3 +145,23 @@ def test_cross_call_overlap_is_exact(rfd, backbone):
         det.sync()
         assert torch.equal(outs[1].buf, refs[0])
     det.close()
+
+
+def test_fresh_contexts_always_have_their_weights(rfd):
+    """Regression (round 3): the device fills of a new context ran on the NULL stream, unordered with the first weight uploads on
+    the context's non-blocking stream; about one fresh context in 16 had layer 0's weights zeroed AFTER they were uploaded --
+    every head constant, no detections, no error.  24 contexts back to back would have caught that 3 times out of 4."""
+    g = rfd.Graph(rfd.BACKBONE_MNET025)
+    frames = [helpers.make_image(77, 400, 520, n_blobs=5)]
+    first = None
+    for k in range(24):
+        det = rfd.RetinaFaceDetection(max_batch_size=1, max_det=256, confidence_threshold=0.3, backbone=rfd.BACKBONE_MNET025)
+        det.init_synthetic_weights(1234)
+        w0, _ = det.get_layer(0, g.layers[0])
+        assert float(np.abs(w0).mean()) > 0, "context %d lost the weights of layer 0" % k
+        d, kps = det.call_batch(frames)[0]
+        if first is None:
+            first = d
+            assert len(d) > 0
+        assert np.array_equal(d, first), k
+        det.close()
