@@ -596,6 +596,229 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
     wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
 }
 
+// ------------------------------------------------------------------------------------------------
+// pw_stream with the NEXT unit's conv1 run back to back on the tile it has just produced (round 3; stage 2's dim-match units:
+// conv3 128 -> 512 + residual, then conv1 512 -> 128 of the following unit).  Per 128-pixel tile and 128-channel chunk c of the
+// raw sum the epilogue, besides storing the chunk, writes relu(raw * scale + shift) -- the producer unit's BN + ReLU, on the
+// bf16-rounded raw value exactly as pw_gemm applies it to its landed tile -- as a bf16 MFMA operand tile [128 px][128 ch] into
+// LDS; two more K steps then accumulate W1[:, chunk c] x that tile into the conv1 accumulators, which live across the chunks.
+// The raw tensor is therefore written once and read once (as the next residual), not twice, and one launch disappears.
+// Same K order and MFMA sequence per output as pw_stream + pw_gemm: bit-identical results.
+// One weight stream carries both layers' 16-KiB steps, per chunk W3(c, 0..NK-1), W1(c, 0), W1(c, 1), a whole chunk ahead in an
+// (NK + 3)-slot ring; the one drain per chunk sits where pw_stream has it (between the conv3 steps and the epilogue).
+// LDS at K3 = 128: X 32 + operand tile 32 + ring 80 KiB + tables 6.5 KiB.
+// ------------------------------------------------------------------------------------------------
+template <int NK>
+__global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
+{
+    constexpr int BM = 128, S = NK + 2, WSLOTS = S + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);   // [NK][BM*64]
+    bf16_t *As = Xs + NK * BM * 64;                  // [2][BM*64]: the activated chunk as conv1's operand (two K steps)
+    bf16_t *Ws = As + 2 * BM * 64;                   // [WSLOTS][128*64]
+    float *Tab = reinterpret_cast<float *>(Ws + WSLOTS * 128 * 64); // bias3 [N] | scale [N] | shift [N] | bias1 [128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int M = p.B * p.Ho * p.Wo, K = p.Cin, N = p.Cout, N1 = 128;
+    const int NC = N >> 7;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+    if ((int)blockIdx.x >= tiles_m) return;
+
+    for (int round = 0; round < (N + 511) / 512; ++round) { // scalar trip count, predicated body (tools/isa_check.py can follow EXEC)
+        const int c = tid + round * 512;
+        if (c < N) {
+            Tab[c] = p.bias[c];
+            Tab[N + c] = p.scale2[c];
+            Tab[2 * N + c] = p.shift2[c];
+        }
+        if (c < N1) Tab[3 * N + c] = p.bias1[c];
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, (uint32_t)((size_t)M * K * 2), 0x00020000);
+    // ONE resource for both filter banks (both live in the network's weight buffer, W1 behind W3: the launcher checks): a
+    // select between two descriptors made hipcc park them in scratch and wrap every DMA in a waterfall loop
+    const uint32_t w1_delta = (uint32_t)((const char *)p.w1 - (const char *)p.w);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, w1_delta + (uint32_t)((size_t)N1 * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, (uint32_t)((size_t)M * N1 * 2), 0x00020000);
+    const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
+    // weight pieces of a step (16 x [8 rows x 128 B]): wave w stages pieces w and w + 8; LDS row rho holds output channel perm(rho)
+    // of the 128-row block (8 consecutive channels per lane in the epilogues); row pitch K for W3, N for W1
+    uint32_t woff[2], woff1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rho = (wave + 8 * q) * 8 + lr;
+        const int rw_ = rho & 63, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        woff[q] = (uint32_t)(((size_t)chn * K + chunk * 8) * 2);
+        woff1[q] = (uint32_t)(((size_t)chn * N + chunk * 8) * 2);
+    }
+    // the unified weight stream: position of the NEXT step to issue; per chunk W3(c, 0..NK-1), W1(c, 0), W1(c, 1); one chunk ahead
+    int wi_nc = 0, wi_s = 0, wi_slot = 0;
+    auto issue_w = [&]() {
+        bf16_t *dst = Ws + wi_slot * 128 * 64;
+        const bool w3 = wi_s < NK; // wave-uniform
+        // W3: rows of chunk wi_nc, columns of K step wi_s; W1: all 128 rows, columns = the channels of chunk wi_nc, half wi_s - NK
+        const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * K + (wi_s << 6)) * 2) : w1_delta + (uint32_t)(((wi_nc << 7) + ((wi_s - NK) << 6)) * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + 8 * q) * 512);
+        if (++wi_s == S) { wi_s = 0; if (++wi_nc == NC) wi_nc = 0; }
+        wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
+    };
+    const uint32_t lane_off = (uint32_t)((((size_t)(wm * 32 + frow)) * N + wn * 64 + fq * 8) * 2);
+    auto issue_res = [&](u32x4 (&r)[4], int mt, int nc) {
+        const bool tile_ok = mt < tiles_m;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = tile_ok && mt * BM + wm * 32 + j * 16 + frow < M;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                asm_buffer_load_b128(r[j * 2 + h], ok ? lane_off + (uint32_t)((((size_t)mt * BM + j * 16) * N + (nc << 7) + h * 32) * 2) : kOob, rres);
+        }
+    };
+
+    u32x4 resA[4], resB[4];
+    issue_res(resA, blockIdx.x, 0);
+#pragma unroll
+    for (int i = 0; i < S; ++i) issue_w(); // the first chunk's steps
+    int cslot = 0; // ring slot of the step consumed next
+
+    // one K step of either GEMM on this wave's 32 x 64 tile: A = ring slot rows wn*64.., B = 128-row operand tile rows wm*32..
+    auto mma_step = [&](f32x4 (&acc)[4][2], const bf16_t *btile) __attribute__((always_inline)) {
+        const bf16_t *xs = btile + (wm * 32) * 64;
+        const bf16_t *ws = Ws + cslot * 128 * 64 + (wn * 64) * 64;
+        cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[2];
+            const int ch = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + frow;
+                af[i] = *reinterpret_cast<const bf16x8 *>(ws + r * 64 + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 16 + frow;
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(xs + r * 64 + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    for (int mt = blockIdx.x; mt < tiles_m; mt += gridDim.x) {
+        const int m0 = mt * BM;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave is done with the previous tile's tiles
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + (wave + 8 * q) * 8 + lr;
+                blds16(rx, m < M ? (uint32_t)(((size_t)m * K + chunk * 8) * 2) : kOob, (uint32_t)(kt << 7), Xs + kt * BM * 64 + (wave + 8 * q) * 512);
+            }
+        wait_vmcnt<0>(); // the activation tile (+ the previous tile's t1 stores)
+        f32x4 acc1[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4]) __attribute__((always_inline)) {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) { // conv3 steps of this chunk
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_w();
+                mma_step(acc, Xs + kt * BM * 64);
+            }
+            // ---- the one drain of the chunk: residual of this chunk, W1 steps of this chunk, stores of the previous one ----
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (nc + 1 < NC) issue_res(nxt, mt, nc + 1);
+            else issue_res(nxt, mt + (int)gridDim.x, 0);
+            const int n0 = nc << 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n0 + wn * 64 + h * 32 + fq * 8;
+                float bias[8], sc[8], sh[8];
+                lds_table_read8(Tab + n, bias);
+                lds_table_read8(Tab + N + n, sc);
+                lds_table_read8(Tab + 2 * N + n, sh);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wm * 32 + j * 16 + frow, m = m0 + row;
+                    const uint32_t off = m < M ? (uint32_t)(((size_t)m * N + n) * 2) : kOob;
+                    const u32x4 rv = cur[j * 2 + h];
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[2 * h][j][k] + bias[k];
+                        v[4 + k] = acc[2 * h + 1][j][k] + bias[4 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
+                        v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
+                    }
+                    const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, off, 0, 0);
+                    // conv1's operand: relu(fma(raw as stored, scale, shift)) -- pw_gemm's input affine, on the same bf16 values
+                    const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+                    float a[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
+                        a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                    }
+                    const uint2 alo = pack_bf16x4(a[0], a[1], a[2], a[3]), ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                    // K step wn of the operand tile (channels wn*64 .. +63 of the chunk), 16-byte slot h*4 + fq of pixel row `row`
+                    *reinterpret_cast<uint4 *>(As + wn * BM * 64 + row * 64 + (((h * 4 + fq) ^ (row & 7)) << 3)) = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+                }
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1) { // conv1 steps on the chunk just activated (the barrier publishes the operand tile)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_w();
+                mma_step(acc1, As + k1 * BM * 64);
+            }
+        };
+        for (int nc = 0; nc < NC; nc += 2) {
+            do_chunk(nc, resA, resB);
+            do_chunk(nc + 1, resB, resA);
+        }
+        // ---- conv1 epilogue: t1 = relu(acc1 + bias1), 16-byte stores (8 consecutive channels of one pixel per lane) ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = wn * 64 + h * 32 + fq * 8;
+            float b1[8];
+            lds_table_read8(Tab + 3 * N + n, b1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + wm * 32 + j * 16 + frow;
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = fmaxf(acc1[2 * h][j][k] + b1[k], 0.f);
+                    o[4 + k] = fmaxf(acc1[2 * h + 1][j][k] + b1[4 + k], 0.f);
+                }
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rt1, m < M ? (uint32_t)(((size_t)m * N1 + n) * 2) : kOob, 0, 0);
+            }
+        }
+    }
+    wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
+}
+
 // CU count of the current device, queried once per device (every persistent launcher sizes its "even share, no tail" grid
 // with it; a partitioned or smaller device simply gets a smaller grid)
 static int device_cus()
@@ -630,7 +853,8 @@ static int persistent_cus(int co_running, bool hbm_bound = false)
 // real need instead -- the configuration that gave nondeterministic images in round 2.
 constexpr size_t kPersistentLds = 160 * 1024;
 static const char *const kPersistentKernels[] = {"pw_stream_kernel", "conv3x3_c64_kernel", "conv3x3_halo_kernel", "pw_gemm_kernel",
-                                                 "pw_wide_kernel", "conv_b2b_s1_persistent_kernel", "conv_b2b_s1_persistent_k128_kernel"};
+                                                 "pw_wide_kernel", "conv_b2b_s1_persistent_kernel", "conv_b2b_s1_persistent_k128_kernel",
+                                                 "pw_b2b_kernel"};
 int persistent_kernel_table(int i, const char **name, size_t *lds_bytes)
 {
     const int n = (int)(sizeof(kPersistentKernels) / sizeof(kPersistentKernels[0]));
@@ -666,6 +890,17 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
     // `s_waitcnt lgkmcnt(0)` + barrier) that the padding may only have masked; the padding stays as the rule either way.
     const size_t lds_need = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
     return launch_persistent<pw_stream_kernel<NK, HAS_Y, HAS_Y2>>(grid, lds_need, s, p);
+}
+static int launch_pw_b2b(const ConvParams &p, hipStream_t s)
+{
+    constexpr int NK = 2;
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = ceil_div(M, 128);
+    const int ncu = persistent_cus(p.co_running, true);
+    const int per = ceil_div(tiles_m, ncu);
+    const int grid = ceil_div(tiles_m, per);
+    const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
+    return launch_persistent<pw_b2b_kernel<NK>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2301,6 +2536,29 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX> static int launch_c
 
 int launch_conv(const ConvParams &p, hipStream_t s)
 {
+    if (p.w1) {
+        // conv3 of a dim-match unit + the next unit's conv1 (OP_B2B beyond stage 1).  One persistent kernel where pw_stream
+        // itself would run (force_tile 7 / 1 / 2 and small batches: two launches; bit-identical either way).
+        const int M1 = p.B * p.Ho * p.Wo;
+        const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin == 128 && p.Cout == 512 && p.Cin2 == 0 && !p.in_scale &&
+                          p.res && !p.res_up2 && !p.res_post && !p.relu && p.y && !p.y2 && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
+                          p.ldy == p.Cout && p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
+                          (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
+        if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) return launch_pw_b2b(p, s);
+        ConvParams a = p;
+        a.w1 = nullptr; a.bias1 = nullptr; a.t1 = nullptr;
+        RFD_TRY(launch_conv(a, s));
+        ConvParams q;
+        memset(&q, 0, sizeof q);
+        q.x = p.y; q.w = p.w1; q.bias = p.bias1; q.zero = p.zero;
+        q.in_scale = p.scale2; q.in_shift = p.shift2;
+        q.y = p.t1;
+        q.B = p.B; q.H = q.Ho = p.Ho; q.W = q.Wo = p.Wo; q.Cin = p.Cout; q.Cout = p.Cin;
+        q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
+        q.ldx = p.Cout; q.ldy = p.Cin; q.y_split = 1 << 30; q.n_valid = 1 << 30; q.relu = 1;
+        q.force_tile = p.force_tile == 16 ? 0 : p.force_tile; q.co_running = p.co_running;
+        return launch_conv(q, s);
+    }
     if (p.Cin % 64 != 0 || p.Cin2 % 64 != 0 || p.Cout % 32 != 0) {
         set_error("conv: Cin=%d must be a multiple of 64 and Cout=%d of 32", p.Cin, p.Cout);
         return RFD_ERR_INVALID_ARG;

@@ -129,7 +129,10 @@ void Graph::build_r50()
             const int t_act = (last || !fuse_act) ? add_tensor(cout, ho, wo) : -1;
             const int o3 = add_conv(l3, t2, t_raw, 0, dim_match ? x_raw : -1, t_act);
             if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
-            if (s == 0 && !last) {
+            // stage 2 (round 3): the same pairing for the dim-match units -- pw_b2b_kernel, or two launches where it does not pay
+            // (RFD_B2B_STAGES=1 keeps it to stage 1: A/B knob)
+            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 2; }();
+            if ((s == 0 || (s == 1 && b2b_stages >= 2 && dim_match && fuse_act)) && !last) {
                 // stage 1: conv3 of this unit and conv1 of the NEXT unit run back to back in one kernel; the
                 // activated 256-channel tile stays in LDS (conv_b2b_s1_kernel)
                 snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 2);
@@ -752,7 +755,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
         } else if (o.kind == OP_STEM) {
             RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
                                 d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s));
-        } else if (o.kind == OP_B2B) {
+        } else if (o.kind == OP_B2B && L.cin_d == 64) {
             const Layer &Lb = g.layers[o.layer_b];
             B2BParams bp;
             memset(&bp, 0, sizeof bp);
@@ -816,6 +819,12 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             p.ldy = o.out >= 0 ? g.tensors[o.out].C : p.Cout;
             p.y_coff = o.y_coff;
             p.relu = o.relu; p.res_up2 = o.res_up2; p.res_post = o.res_post; p.head_softmax = o.head_softmax;
+            if (o.kind == OP_B2B) { // beyond stage 1: the pair runs through launch_conv (pw_b2b_kernel, or two launches)
+                const Layer &Lb = g.layers[o.layer_b];
+                p.w1 = d_w + Lb.w_off;
+                p.bias1 = d_b + Lb.b_off;
+                p.t1 = (bf16_t *)tensor_ptr(o.out_b, batch_off);
+            }
             RFD_TRY(launch_conv(p, s));
         }
         if (profiling) RFD_HIP(hipEventRecord(ev[2 * i + 1], s));
