@@ -608,7 +608,9 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 // (NK + 3)-slot ring; the one drain per chunk sits where pw_stream has it (between the conv3 steps and the epilogue).
 // LDS at K3 = 128: X 32 + operand tile 32 + ring 80 KiB + tables 6.5 KiB.
 // ------------------------------------------------------------------------------------------------
-template <int NK>
+// ACT_OUT (the LAST unit of a stage: stage 1 -> stage 2's first conv1, 256 -> 128 at 160 x 160): the unit stores its BN + ReLU
+// output (y2, pw_stream's arithmetic: v * scale + shift, ReLU) instead of the raw sum, and that stored value IS conv1's operand.
+template <int NK, bool ACT_OUT>
 __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 {
     constexpr int BM = 128, S = NK + 2, WSLOTS = S + 1;
@@ -643,7 +645,7 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
     // select between two descriptors made hipcc park them in scratch and wrap every DMA in a waterfall loop
     const uint32_t w1_delta = (uint32_t)((const char *)p.w1 - (const char *)p.w);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, w1_delta + (uint32_t)((size_t)N1 * N * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ACT_OUT ? p.y2 : p.y, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, (uint32_t)((size_t)M * N1 * 2), 0x00020000);
     const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
     // weight pieces of a step (16 x [8 rows x 128 B]): wave w stages pieces w and w + 8; LDS row rho holds output channel perm(rho)
@@ -770,17 +772,26 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
                         v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
                         v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
                     }
-                    const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, off, 0, 0);
-                    // conv1's operand: relu(fma(raw as stored, scale, shift)) -- pw_gemm's input affine, on the same bf16 values
-                    const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
-                    float a[8];
+                    uint2 alo, ahi;
+                    if (ACT_OUT) { // the stage output relu(v * scale + shift) (pw_stream's y2), stored and used as the operand
+                        float a[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
-                        a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        for (int k = 0; k < 8; ++k) a[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+                        alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{alo.x, alo.y, ahi.x, ahi.y}, ry, off, 0, 0);
+                    } else {
+                        const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, off, 0, 0);
+                        // conv1's operand: relu(fma(raw as stored, scale, shift)) -- pw_gemm's input affine, on the same bf16 values
+                        const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+                        float a[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
+                            a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        }
+                        alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
                     }
-                    const uint2 alo = pack_bf16x4(a[0], a[1], a[2], a[3]), ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
                     // K step wn of the operand tile (channels wn*64 .. +63 of the chunk), 16-byte slot h*4 + fq of pixel row `row`
                     *reinterpret_cast<uint4 *>(As + wn * BM * 64 + row * 64 + (((h * 4 + fq) ^ (row & 7)) << 3)) = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
                 }
@@ -891,16 +902,15 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
     const size_t lds_need = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
     return launch_persistent<pw_stream_kernel<NK, HAS_Y, HAS_Y2>>(grid, lds_need, s, p);
 }
-static int launch_pw_b2b(const ConvParams &p, hipStream_t s)
+template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hipStream_t s)
 {
-    constexpr int NK = 2;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
     const int ncu = persistent_cus(p.co_running, true);
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
     const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
-    return launch_persistent<pw_b2b_kernel<NK>>(grid, lds_need, s, p);
+    return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2540,22 +2550,27 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         // conv3 of a dim-match unit + the next unit's conv1 (OP_B2B beyond stage 1).  One persistent kernel where pw_stream
         // itself would run (force_tile 7 / 1 / 2 and small batches: two launches; bit-identical either way).
         const int M1 = p.B * p.Ho * p.Wo;
-        const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cin == 128 && p.Cout == 512 && p.Cin2 == 0 && !p.in_scale &&
-                          p.res && !p.res_up2 && !p.res_post && !p.relu && p.y && !p.y2 && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
-                          p.ldy == p.Cout && p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
+        // two shapes: (i) a middle unit of stage 2: 128 -> 512, raw sum out, conv1 512 -> 128 on relu(BN(raw));
+        //             (ii) the last unit of stage 1: 64 -> 256, activated output only, conv1 256 -> 128 of stage 2's first unit on it
+        const bool act_out = !p.y && p.y2;
+        const bool shape = act_out ? (p.Cin == 64 && p.Cout == 256) : (p.Cin == 128 && p.Cout == 512 && p.y && !p.y2 && p.ldy == p.Cout);
+        const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && shape && p.Cin2 == 0 && !p.in_scale &&
+                          p.res && !p.res_up2 && !p.res_post && !p.relu && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
+                          p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
                           (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
-        if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) return launch_pw_b2b(p, s);
+        if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30))
+            return act_out ? launch_pw_b2b<1, true>(p, s) : launch_pw_b2b<2, false>(p, s);
         ConvParams a = p;
         a.w1 = nullptr; a.bias1 = nullptr; a.t1 = nullptr;
         RFD_TRY(launch_conv(a, s));
         ConvParams q;
         memset(&q, 0, sizeof q);
-        q.x = p.y; q.w = p.w1; q.bias = p.bias1; q.zero = p.zero;
-        q.in_scale = p.scale2; q.in_shift = p.shift2;
+        q.x = act_out ? p.y2 : p.y; q.w = p.w1; q.bias = p.bias1; q.zero = p.zero;
+        if (!act_out) { q.in_scale = p.scale2; q.in_shift = p.shift2; }
         q.y = p.t1;
-        q.B = p.B; q.H = q.Ho = p.Ho; q.W = q.Wo = p.Wo; q.Cin = p.Cout; q.Cout = p.Cin;
+        q.B = p.B; q.H = q.Ho = p.Ho; q.W = q.Wo = p.Wo; q.Cin = p.Cout; q.Cout = 128;
         q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
-        q.ldx = p.Cout; q.ldy = p.Cin; q.y_split = 1 << 30; q.n_valid = 1 << 30; q.relu = 1;
+        q.ldx = p.Cout; q.ldy = 128; q.y_split = 1 << 30; q.n_valid = 1 << 30; q.relu = 1;
         q.force_tile = p.force_tile == 16 ? 0 : p.force_tile; q.co_running = p.co_running;
         return launch_conv(q, s);
     }

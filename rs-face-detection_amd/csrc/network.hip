@@ -131,7 +131,14 @@ void Graph::build_r50()
             if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
             // stage 2 (round 3): the same pairing for the dim-match units -- pw_b2b_kernel, or two launches where it does not pay
             // (RFD_B2B_STAGES=1 keeps it to stage 1: A/B knob)
-            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 2; }();
+            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 3; }(); // 1: stage 1 only; 2: + stage 2's middle units; 3: + stage 1 -> 2
+            if (s == 0 && last && b2b_stages >= 3 && units[1] > 0) {
+                // the last unit of stage 1 with stage 2's first conv1 (256 -> 128 at 160 x 160, on the stage output): pw_b2b_kernel
+                snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 2, 1);
+                const int l1n = add_layer(nm, cout, mids[s + 1], 1, 1, 0, 1.0f, 0);
+                b2b_t1 = add_tensor(mids[s + 1], ho, wo);
+                ops[o3].kind = OP_B2B; ops[o3].layer_b = l1n; ops[o3].out_b = b2b_t1;
+            }
             if ((s == 0 || (s == 1 && b2b_stages >= 2 && dim_match && fuse_act)) && !last) {
                 // stage 1: conv3 of this unit and conv1 of the NEXT unit run back to back in one kernel; the
                 // activated 256-channel tile stays in LDS (conv_b2b_s1_kernel)
@@ -755,7 +762,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
         } else if (o.kind == OP_STEM) {
             RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
                                 d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s));
-        } else if (o.kind == OP_B2B && L.cin_d == 64) {
+        } else if (o.kind == OP_B2B && L.cin_d == 64 && g.layers[o.layer_b].cout_d == 64) {
             const Layer &Lb = g.layers[o.layer_b];
             B2BParams bp;
             memset(&bp, 0, sizeof bp);
@@ -900,19 +907,21 @@ int Network::run_f32(int B, hipStream_t s, int first_op, int last_op, int batch_
         p.y_coff = o.y_coff;
         p.relu = o.relu; p.res_up2 = o.res_up2; p.res_post = o.res_post; p.head_softmax = o.head_softmax;
         if (o.kind == OP_B2B) { // raw = conv3(x) [+ shortcut(x2)] + bias (+ res); t1 = relu(conv1(relu(raw * scale + shift)) + bias1)
-            p.relu = 0; p.y2 = nullptr; p.yf = nullptr;
+            const bool act_out = o.out < 0; // last unit of a stage: only the activated output exists and conv1 reads it as it is
+            p.relu = 0; p.yf = nullptr;
+            if (!act_out) p.y2 = nullptr;
             p.n_valid = p.Cout; p.y_split = 1 << 30; p.y_split_add = 0; p.y_coff = 0; p.ldy = p.Cout;
             RFD_TRY(launch_conv_f32(p, s));
             const Layer &Lb = g.layers[o.layer_b];
             ConvF32Params q;
             memset(&q, 0, sizeof q);
-            q.x = (const float *)tensor_ptr32(o.out, batch_off);
+            q.x = (const float *)tensor_ptr32(act_out ? o.out2 : o.out, batch_off);
             q.w = d_w32 + Lb.w_off; q.ldw = (int)Lb.ldw; q.bias = d_b + Lb.b_off;
-            q.in_scale = aff + L.a_off; q.in_shift = aff + L.a_off + L.cout_d;
+            if (!act_out) { q.in_scale = aff + L.a_off; q.in_shift = aff + L.a_off + L.cout_d; }
             q.y = (float *)tensor_ptr32(o.out_b, batch_off);
             q.B = B; q.H = q.Ho = tin.H; q.W = q.Wo = tin.W; q.Cin = Lb.cin_d; q.Cout = Lb.cout_d;
             q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
-            q.ldx = g.tensors[o.out].C; q.ldy = g.tensors[o.out_b].C; q.n_valid = q.Cout; q.y_split = 1 << 30; q.relu = 1;
+            q.ldx = g.tensors[act_out ? o.out2 : o.out].C; q.ldy = g.tensors[o.out_b].C; q.n_valid = q.Cout; q.y_split = 1 << 30; q.relu = 1;
             RFD_TRY(launch_conv_f32(q, s));
             continue;
         }

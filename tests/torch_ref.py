@@ -101,7 +101,10 @@ class TorchRef:
             tensors[o.out2] = bf16r(F.relu(v * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
         if o.kind == 6:  # back to back: the next unit's conv1 on relu(affine(bf16 raw)), bias + relu
             s, tt = self.aff[o.layer]
-            a = bf16r(F.relu(tensors[o.out] * s.view(1, -1, 1, 1) + tt.view(1, -1, 1, 1)))
+            if o.out >= 0:
+                a = bf16r(F.relu(tensors[o.out] * s.view(1, -1, 1, 1) + tt.view(1, -1, 1, 1)))
+            else:            # the last unit of a stage: only the activated output exists; conv1 reads it as stored
+                a = tensors[o.out2]
             tensors[o.out_b] = bf16r(F.relu(F.conv2d(a, self.w[o.layer_b], self.b[o.layer_b])))
         if o.outf >= 0:
             if o.head_softmax:  # channels 0,1 = bg(a), 2,3 = fg(a): softmax over the pairs (a, A+a)
