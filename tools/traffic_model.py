@@ -60,7 +60,8 @@ for i, o in enumerate(g.ops):
     if o.kind == 3:
         k = "rfd::stem_kernel"
     elif o.kind == 6:
-        k = "rfd::conv_b2b_s1_kernel"
+        Lb = g.layers[o.layer_b]
+        k = "rfd::conv_b2b_s1_kernel" if (L.cin == 64 and Lb.cout == 64) else "rfd::pw_b2b_kernel"  # stage 1's own kernels / round 3's pair kernel
     elif o.kind != 2:
         continue
     else:
