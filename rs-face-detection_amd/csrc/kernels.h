@@ -140,7 +140,7 @@ struct ConvParams {
     int k_chunk_major;    // set by launch_conv: K order (chunk, ky, kx) instead of (ky, kx, chunk) (see conv_igemm_kernel)
     // back-to-back pair (OP_B2B beyond stage 1): after this 1x1 conv3 (+ residual -> y = the raw sum), the NEXT unit's conv1 on
     // relu(y * scale2 + shift2) -- or, for the last unit of a stage (y null), on its activated output y2 --:
-    // t1 = relu(W1 . act + bias1), [B][H][W][128].
+    // t1 = relu(W1 . act + bias1), [B][H][W][N1], N1 = the next unit's bottleneck width (this Cin; 128 for the stage 1 -> 2 boundary).
     // launch_conv runs the pair in one kernel (pw_b2b_kernel) where that pays and as two launches otherwise: same bits.
     const bf16_t *w1;     // [Cin][Cout] (row pitch Cout), or null: no pair
     const float *bias1;

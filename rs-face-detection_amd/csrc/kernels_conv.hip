@@ -830,6 +830,220 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
     wait_vmcnt<0>(); // the weight steps and residual loads issued beyond the end
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pair (a unit's conv3 + residual, then the next unit's conv1) with the tile cut the other way: every wave owns 16 PIXELS
+// and all channels.  Its activation tile [16 px][K3] lives in registers as MFMA B fragments (loaded once per tile straight from
+// global memory), and the epilogue's lane layout -- pixel = lane % 16, eight consecutive channels per lane and 32-channel group
+// -- IS the B-fragment layout of conv1's K slices, so the activated chunk feeds the second GEMM from registers: no activation
+// tile and no operand tile in LDS at all.  LDS holds only the weight ring, which therefore has room for a whole chunk of BOTH
+// layers even at K3 = 256: 8 slot-steps of 16 KiB + 1 = 144 KiB (pw_b2b_kernel's layout needs 64 + 32 KiB of tiles there and
+// cannot).  Price: every wave reads every weight row from LDS (one fragment read per MFMA instead of one per two): the kernel is
+// LDS-read bound at about the time its HBM bytes take, which is what these layers are bound by anyway.
+// Per slot-step [128 rows][64 k]: 16 fragment reads, 16 MFMAs per wave; one barrier; the stream a whole chunk ahead; one drain
+// per chunk.  Same K order per output as pw_stream + pw_gemm: bit-identical.  NK = K3 / 64, N1B = N1 / 128.
+// ------------------------------------------------------------------------------------------------
+template <int NK, int N1B, bool ACT_OUT>
+__global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
+{
+    constexpr int BM = 128, S = NK + 2 * N1B, WSLOTS = S + 1, N1 = 128 * N1B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Ws = reinterpret_cast<bf16_t *>(smem);                    // [WSLOTS][128*64]
+    float *Tab = reinterpret_cast<float *>(Ws + WSLOTS * 128 * 64);  // bias3 [N] | scale [N] | shift [N] | bias1 [N1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.B * p.Ho * p.Wo, K = p.Cin, N = p.Cout;
+    const int NC = N >> 7;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
+    if ((int)blockIdx.x >= tiles_m) return;
+
+    for (int round = 0; round < (N + 511) / 512; ++round) { // scalar trip count, predicated body
+        const int c = tid + round * 512;
+        if (c < N) {
+            Tab[c] = p.bias[c];
+            Tab[N + c] = p.scale2[c];
+            Tab[2 * N + c] = p.shift2[c];
+        }
+        if (c < N1) Tab[3 * N + c] = p.bias1[c];
+    }
+    __syncthreads();
+
+    const uint32_t w1_delta = (uint32_t)((const char *)p.w1 - (const char *)p.w); // one descriptor over both filter banks (see pw_b2b_kernel)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, w1_delta + (uint32_t)((size_t)N1 * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ACT_OUT ? p.y2 : p.y, 0, (uint32_t)((size_t)M * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, (uint32_t)((size_t)M * N1 * 2), 0x00020000);
+    const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
+    const u32x4 rxs = make_srd(p.x, (uint32_t)((size_t)M * K * 2));
+    uint32_t woff[2], woff1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rho = (wave + 8 * q) * 8 + lr;
+        const int rw_ = rho & 63, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
+        const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
+        woff[q] = (uint32_t)(((size_t)chn * K + chunk * 8) * 2);
+        woff1[q] = (uint32_t)(((size_t)chn * N + chunk * 8) * 2);
+    }
+    // unified weight stream, per chunk: W3(c, 0..NK-1), then for each 64-channel half k of the chunk and each 128-row block r of
+    // W1: W1(r, k); position of the NEXT step to issue
+    int wi_nc = 0, wi_s = 0, wi_slot = 0;
+    auto issue_w = [&]() {
+        bf16_t *dst = Ws + wi_slot * 128 * 64;
+        const bool w3 = wi_s < NK; // wave-uniform
+        const int s1 = wi_s - NK, k1 = s1 / N1B, r1 = s1 - k1 * N1B;
+        const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * K + (wi_s << 6)) * 2)
+                               : w1_delta + (uint32_t)((((size_t)r1 * 128) * N + (wi_nc << 7) + (k1 << 6)) * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + 8 * q) * 512);
+        if (++wi_s == S) { wi_s = 0; if (++wi_nc == NC) wi_nc = 0; }
+        wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
+    };
+    // this lane: pixel row wave*16 + frow of the tile; per chunk its four 8-channel groups h*32 + fq*8 (h = 0..3)
+    auto issue_res = [&](u32x4 (&r)[4], int mt, int nc) {
+        const int m = mt * BM + wave * 16 + frow;
+        const bool ok = mt < tiles_m && m < M;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            asm_buffer_load_b128(r[h], ok ? (uint32_t)(((size_t)m * N + (nc << 7) + h * 32 + fq * 8) * 2) : kOob, rres);
+    };
+    u32x4 xq[NK * 2]; // the activation tile of this wave as B fragments: K slice q = channels q*32 + fq*8 .. +7 of pixel `frow`
+    auto issue_x = [&](int mt) {
+        const int m = mt * BM + wave * 16 + frow;
+        const bool ok = mt < tiles_m && m < M;
+#pragma unroll
+        for (int q = 0; q < NK * 2; ++q) asm_buffer_load_b128(xq[q], ok ? (uint32_t)(((size_t)m * K + q * 32 + fq * 8) * 2) : kOob, rxs);
+    };
+
+    u32x4 resA[4], resB[4];
+    issue_x(blockIdx.x);
+    issue_res(resA, blockIdx.x, 0);
+#pragma unroll
+    for (int i = 0; i < S; ++i) issue_w(); // the first chunk's steps
+    int cslot = 0;
+    const int arow = frow * 64; // A fragment of row block i: row i*16 + frow; 16-byte slot (kk*4 + fq) ^ (row & 7), row & 7 = frow & 7
+
+    for (int mt = blockIdx.x; mt < tiles_m; mt += gridDim.x) {
+        const int m = mt * BM + wave * 16 + frow;
+        f32x4 acc1[8 * N1B];
+#pragma unroll
+        for (int i = 0; i < 8 * N1B; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the tile's activation fragments (requested during the previous tile's last chunk, or before the loop) and everything older
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4], bool last_chunk) __attribute__((always_inline)) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) { // conv3 steps: all 128 rows of the slot against this wave's 16 pixels
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_w();
+                const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
+                cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, xq[kt * 2 + kk]);
+                    const int so = ((kk * 4 + fq) ^ (frow & 7)) << 3;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 1024 + so);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            // the next tile's activation fragments may be requested as soon as this tile's last conv3 step has read them
+            if (last_chunk) issue_x(mt + (int)gridDim.x);
+            // ---- the one drain of the chunk: residual of this chunk, W1 steps of this chunk, stores of the previous one ----
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last_chunk) issue_res(nxt, mt, nc + 1);
+            else issue_res(nxt, mt + (int)gridDim.x, 0);
+            u32x4 actq[4]; // conv1's B fragments: the activated chunk, K slice h = channels h*32 + fq*8 .. +7 of this pixel
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int n = (nc << 7) + h * 32 + fq * 8;
+                float bias[8], sc[8], sh[8];
+                lds_table_read8(Tab + n, bias);
+                lds_table_read8(Tab + N + n, sc);
+                lds_table_read8(Tab + 2 * N + n, sh);
+                const uint32_t off = m < M ? (uint32_t)(((size_t)m * N + n) * 2) : kOob;
+                const u32x4 rv = cur[h];
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[2 * h][k] + bias[k];
+                    v[4 + k] = acc[2 * h + 1][k] + bias[4 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
+                    v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
+                }
+                uint2 alo, ahi;
+                if (ACT_OUT) {
+                    float a[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+                    alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{alo.x, alo.y, ahi.x, ahi.y}, ry, off, 0, 0);
+                } else {
+                    const uint2 lo = pack_bf16x4(v[0], v[1], v[2], v[3]), hi = pack_bf16x4(v[4], v[5], v[6], v[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, off, 0, 0);
+                    const uint32_t rb[4] = {lo.x, lo.y, hi.x, hi.y};
+                    float a[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
+                        a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                    }
+                    alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
+                }
+                actq[h] = u32x4{alo.x, alo.y, ahi.x, ahi.y};
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1)       // conv1: the chunk's 64-channel half k1 ...
+#pragma unroll
+                for (int r1 = 0; r1 < N1B; ++r1) { // ... against the 128-row block r1 of W1 (one slot-step)
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    issue_w();
+                    const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
+                    cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, actq[k1 * 2 + kk]);
+                        const int so = ((kk * 4 + fq) ^ (frow & 7)) << 3;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 1024 + so);
+                            acc1[r1 * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1[r1 * 8 + i], 0, 0, 0);
+                        }
+                    }
+                }
+        };
+        for (int nc = 0; nc < NC; nc += 2) {
+            do_chunk(nc, resA, resB, false);
+            do_chunk(nc + 1, resB, resA, nc + 2 >= NC);
+        }
+        // ---- conv1 epilogue: t1 = relu(acc1 + bias1): per 128-row block four 8-channel groups of this pixel ----
+#pragma unroll
+        for (int r1 = 0; r1 < N1B; ++r1)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int n = r1 * 128 + h * 32 + fq * 8;
+                float b1[8];
+                lds_table_read8(Tab + 3 * N + n, b1);
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = fmaxf(acc1[r1 * 8 + 2 * h][k] + b1[k], 0.f);
+                    o[4 + k] = fmaxf(acc1[r1 * 8 + 2 * h + 1][k] + b1[4 + k], 0.f);
+                }
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rt1, m < M ? (uint32_t)(((size_t)m * N1 + n) * 2) : kOob, 0, 0);
+            }
+    }
+    wait_vmcnt<0>(); // weight steps, residual and activation loads issued beyond the end
+}
+
 // CU count of the current device, queried once per device (every persistent launcher sizes its "even share, no tail" grid
 // with it; a partitioned or smaller device simply gets a smaller grid)
 static int device_cus()
@@ -865,7 +1079,7 @@ static int persistent_cus(int co_running, bool hbm_bound = false)
 constexpr size_t kPersistentLds = 160 * 1024;
 static const char *const kPersistentKernels[] = {"pw_stream_kernel", "conv3x3_c64_kernel", "conv3x3_halo_kernel", "pw_gemm_kernel",
                                                  "pw_wide_kernel", "conv_b2b_s1_persistent_kernel", "conv_b2b_s1_persistent_k128_kernel",
-                                                 "pw_b2b_kernel"};
+                                                 "pw_b2b_kernel", "pw_pair_kernel"};
 int persistent_kernel_table(int i, const char **name, size_t *lds_bytes)
 {
     const int n = (int)(sizeof(kPersistentKernels) / sizeof(kPersistentKernels[0]));
@@ -911,6 +1125,16 @@ template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hi
     const int grid = ceil_div(tiles_m, per);
     const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
     return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
+}
+template <int NK, int N1B, bool ACT_OUT> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = ceil_div(M, 128);
+    const int ncu = persistent_cus(p.co_running, true);
+    const int per = ceil_div(tiles_m, ncu);
+    const int grid = ceil_div(tiles_m, per);
+    const size_t lds_need = (size_t)(NK + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
+    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2553,13 +2777,20 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         // two shapes: (i) a middle unit of stage 2: 128 -> 512, raw sum out, conv1 512 -> 128 on relu(BN(raw));
         //             (ii) the last unit of stage 1: 64 -> 256, activated output only, conv1 256 -> 128 of stage 2's first unit on it
         const bool act_out = !p.y && p.y2;
-        const bool shape = act_out ? (p.Cin == 64 && p.Cout == 256) : (p.Cin == 128 && p.Cout == 512 && p.y && !p.y2 && p.ldy == p.Cout);
+        const bool s3 = !act_out && p.Cin == 256 && p.Cout == 1024 && p.y && !p.y2 && p.ldy == p.Cout; // stage 3's middle units: pw_pair_kernel only
+        const bool shape = s3 || (act_out ? (p.Cin == 64 && p.Cout == 256) : (p.Cin == 128 && p.Cout == 512 && p.y && !p.y2 && p.ldy == p.Cout));
+        const int N1 = act_out ? 128 : p.Cin;
+        // RFD_PW_PAIR=1: pw_pair_kernel for every pair (A/B against pw_b2b_kernel); default: stage 3 only
+        static const int pair_all = [] { const char *e = getenv("RFD_PW_PAIR"); return e ? atoi(e) : 0; }();
         const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && shape && p.Cin2 == 0 && !p.in_scale &&
                           p.res && !p.res_up2 && !p.res_post && !p.relu && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
                           p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
                           (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
-        if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30))
+        if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) {
+            if (s3) return launch_pw_pair<4, 2, false>(p, s);
+            if (pair_all) return act_out ? launch_pw_pair<1, 1, true>(p, s) : launch_pw_pair<2, 1, false>(p, s);
             return act_out ? launch_pw_b2b<1, true>(p, s) : launch_pw_b2b<2, false>(p, s);
+        }
         ConvParams a = p;
         a.w1 = nullptr; a.bias1 = nullptr; a.t1 = nullptr;
         RFD_TRY(launch_conv(a, s));
@@ -2568,9 +2799,9 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         q.x = act_out ? p.y2 : p.y; q.w = p.w1; q.bias = p.bias1; q.zero = p.zero;
         if (!act_out) { q.in_scale = p.scale2; q.in_shift = p.shift2; }
         q.y = p.t1;
-        q.B = p.B; q.H = q.Ho = p.Ho; q.W = q.Wo = p.Wo; q.Cin = p.Cout; q.Cout = 128;
+        q.B = p.B; q.H = q.Ho = p.Ho; q.W = q.Wo = p.Wo; q.Cin = p.Cout; q.Cout = N1;
         q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
-        q.ldx = p.Cout; q.ldy = 128; q.y_split = 1 << 30; q.n_valid = 1 << 30; q.relu = 1;
+        q.ldx = p.Cout; q.ldy = N1; q.y_split = 1 << 30; q.n_valid = 1 << 30; q.relu = 1;
         q.force_tile = p.force_tile == 16 ? 0 : p.force_tile; q.co_running = p.co_running;
         return launch_conv(q, s);
     }
