@@ -61,7 +61,8 @@ for i, o in enumerate(g.ops):
         k = "rfd::stem_kernel"
     elif o.kind == 6:
         Lb = g.layers[o.layer_b]
-        k = "rfd::conv_b2b_s1_kernel" if (L.cin == 64 and Lb.cout == 64) else "rfd::pw_b2b_kernel"  # stage 1's own kernels / round 3's pair kernel
+        # stage 1's own kernels / round 3's pair kernels (stage 3: the register-operand form)
+        k = "rfd::conv_b2b_s1_kernel" if (L.cin == 64 and Lb.cout == 64) else ("rfd::pw_pair_kernel" if L.cin == 256 else "rfd::pw_b2b_kernel")
     elif o.kind != 2:
         continue
     else:
