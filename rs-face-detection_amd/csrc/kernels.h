@@ -142,9 +142,10 @@ struct ConvParams {
     // relu(y * scale2 + shift2) -- or, for the last unit of a stage (y null), on its activated output y2 --:
     // t1 = relu(W1 . act + bias1), [B][H][W][N1], N1 = the next unit's bottleneck width (this Cin; 128 for the stage 1 -> 2 boundary).
     // launch_conv runs the pair in one kernel (pw_b2b_kernel) where that pays and as two launches otherwise: same bits.
-    const bf16_t *w1;     // [Cin][Cout] (row pitch Cout), or null: no pair
+    const bf16_t *w1;     // [n1][Cout] (row pitch Cout), or null: no pair
     const float *bias1;
     bf16_t *t1;
+    int n1;               // conv1's output channels (128 or 256)
 };
 int launch_conv(const ConvParams &p, hipStream_t s);
 // entry i of the list of persistent kernels (name prefix, dynamic LDS every launch of it requests); returns the list length

@@ -2778,8 +2778,9 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         //             (ii) the last unit of stage 1: 64 -> 256, activated output only, conv1 256 -> 128 of stage 2's first unit on it
         const bool act_out = !p.y && p.y2;
         const bool s3 = !act_out && p.Cin == 256 && p.Cout == 1024 && p.y && !p.y2 && p.ldy == p.Cout; // stage 3's middle units: pw_pair_kernel only
-        const bool shape = s3 || (act_out ? (p.Cin == 64 && p.Cout == 256) : (p.Cin == 128 && p.Cout == 512 && p.y && !p.y2 && p.ldy == p.Cout));
-        const int N1 = act_out ? 128 : p.Cin;
+        const bool b23 = act_out && p.Cin == 128 && p.Cout == 512 && p.n1 == 256;                     // stage 2 -> 3 boundary: pw_pair_kernel only
+        const bool shape = s3 || b23 || (act_out ? (p.Cin == 64 && p.Cout == 256 && p.n1 == 128) : (p.Cin == 128 && p.Cout == 512 && p.n1 == 128 && p.y && !p.y2 && p.ldy == p.Cout));
+        const int N1 = p.n1;
         // RFD_PW_PAIR=1: pw_pair_kernel for every pair (A/B against pw_b2b_kernel); default: stage 3 only
         static const int pair_all = [] { const char *e = getenv("RFD_PW_PAIR"); return e ? atoi(e) : 0; }();
         const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && shape && p.Cin2 == 0 && !p.in_scale &&
@@ -2787,7 +2788,8 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                           p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
                           (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
         if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) {
-            if (s3) return launch_pw_pair<4, 2, false>(p, s);
+            if (s3) return p.n1 == 256 ? launch_pw_pair<4, 2, false>(p, s) : RFD_ERR_INVALID_ARG;
+            if (b23) return launch_pw_pair<2, 2, true>(p, s);
             if (pair_all) return act_out ? launch_pw_pair<1, 1, true>(p, s) : launch_pw_pair<2, 1, false>(p, s);
             return act_out ? launch_pw_b2b<1, true>(p, s) : launch_pw_b2b<2, false>(p, s);
         }

@@ -131,9 +131,10 @@ void Graph::build_r50()
             if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
             // stage 2 (round 3): the same pairing for the dim-match units -- pw_b2b_kernel, or two launches where it does not pay
             // (RFD_B2B_STAGES=1 keeps it to stage 1: A/B knob)
-            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 4; }(); // 1: stage 1 only; 2: + stage 2's middle units; 3: + stage 1 -> 2; 4: + stage 3's middle units
-            if (s == 0 && last && b2b_stages >= 3 && units[1] > 0) {
-                // the last unit of stage 1 with stage 2's first conv1 (256 -> 128 at 160 x 160, on the stage output): pw_b2b_kernel
+            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 5; }(); // 1: stage 1 only; 2: + stage 2's middle units; 3: + stage 1 -> 2; 4: + stage 3's middle units; 5: + stage 2 -> 3
+            if ((s == 0 && last && b2b_stages >= 3) || (s == 1 && last && b2b_stages >= 5)) {
+                // the last unit of stage 1 with stage 2's first conv1 (256 -> 128 at 160 x 160, on the stage output): pw_b2b_kernel;
+                // the last unit of stage 2 with stage 3's first conv1 (512 -> 256 at 80 x 80): pw_pair_kernel
                 snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 2, 1);
                 const int l1n = add_layer(nm, cout, mids[s + 1], 1, 1, 0, 1.0f, 0);
                 b2b_t1 = add_tensor(mids[s + 1], ho, wo);
@@ -831,6 +832,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
                 p.w1 = d_w + Lb.w_off;
                 p.bias1 = d_b + Lb.b_off;
                 p.t1 = (bf16_t *)tensor_ptr(o.out_b, batch_off);
+                p.n1 = Lb.cout_d;
             }
             RFD_TRY(launch_conv(p, s));
         }
