@@ -842,17 +842,20 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 // Per slot-step [128 rows][64 k]: 16 fragment reads, 16 MFMAs per wave; one barrier; the stream a whole chunk ahead; one drain
 // per chunk.  Same K order per output as pw_stream + pw_gemm: bit-identical.  NK = K3 / 64, N1B = N1 / 128.
 // ------------------------------------------------------------------------------------------------
-template <int NK, int N1B, bool ACT_OUT>
+// NK2 > 0: the first unit of a stage -- the 1x1 stride-2 shortcut conv rides in the same GEMM as a second K segment (NK2 more K
+// steps whose activation fragments are gathered from x2 at (2 ho, 2 wo)), its bias is added to conv3's, and there is no residual.
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0>
 __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
 {
-    constexpr int BM = 128, S = NK + 2 * N1B, WSLOTS = S + 1, N1 = 128 * N1B;
+    constexpr int BM = 128, NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = S + 1, N1 = 128 * N1B;
+    constexpr bool HAS_RES = NK2 == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Ws = reinterpret_cast<bf16_t *>(smem);                    // [WSLOTS][128*64]
     float *Tab = reinterpret_cast<float *>(Ws + WSLOTS * 128 * 64);  // bias3 [N] | scale [N] | shift [N] | bias1 [N1]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int M = p.B * p.Ho * p.Wo, K = p.Cin, N = p.Cout;
+    const int M = p.B * p.Ho * p.Wo, K = p.Cin, N = p.Cout, KT = p.Cin + (NK2 ? p.Cin2 : 0);
     const int NC = N >> 7;
     const int tiles_m = (M + BM - 1) / BM;
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
@@ -861,7 +864,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     for (int round = 0; round < (N + 511) / 512; ++round) { // scalar trip count, predicated body
         const int c = tid + round * 512;
         if (c < N) {
-            Tab[c] = p.bias[c];
+            Tab[c] = NK2 ? p.bias[c] + p.bias2[c] : p.bias[c]; // conv_epilogue adds the two biases first, then the accumulator
             Tab[N + c] = p.scale2[c];
             Tab[2 * N + c] = p.shift2[c];
         }
@@ -875,13 +878,14 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, (uint32_t)((size_t)M * N1 * 2), 0x00020000);
     const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
     const u32x4 rxs = make_srd(p.x, (uint32_t)((size_t)M * K * 2));
+    const u32x4 rxs2 = make_srd(NK2 ? p.x2 : p.x, (uint32_t)(NK2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0));
     uint32_t woff[2], woff1[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int rho = (wave + 8 * q) * 8 + lr;
         const int rw_ = rho & 63, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
         const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
-        woff[q] = (uint32_t)(((size_t)chn * K + chunk * 8) * 2);
+        woff[q] = (uint32_t)(((size_t)chn * KT + chunk * 8) * 2);
         woff1[q] = (uint32_t)(((size_t)chn * N + chunk * 8) * 2);
     }
     // unified weight stream, per chunk: W3(c, 0..NK-1), then for each 64-channel half k of the chunk and each 128-row block r of
@@ -889,9 +893,9 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     int wi_nc = 0, wi_s = 0, wi_slot = 0;
     auto issue_w = [&]() {
         bf16_t *dst = Ws + wi_slot * 128 * 64;
-        const bool w3 = wi_s < NK; // wave-uniform
-        const int s1 = wi_s - NK, k1 = s1 / N1B, r1 = s1 - k1 * N1B;
-        const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * K + (wi_s << 6)) * 2)
+        const bool w3 = wi_s < NKT; // wave-uniform
+        const int s1 = wi_s - NKT, k1 = s1 / N1B, r1 = s1 - k1 * N1B;
+        const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * KT + (wi_s << 6)) * 2)
                                : w1_delta + (uint32_t)((((size_t)r1 * 128) * N + (wi_nc << 7) + (k1 << 6)) * 2);
 #pragma unroll
         for (int q = 0; q < 2; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + 8 * q) * 512);
@@ -900,21 +904,28 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     };
     // this lane: pixel row wave*16 + frow of the tile; per chunk its four 8-channel groups h*32 + fq*8 (h = 0..3)
     auto issue_res = [&](u32x4 (&r)[4], int mt, int nc) {
+        if (!HAS_RES) return;
         const int m = mt * BM + wave * 16 + frow;
         const bool ok = mt < tiles_m && m < M;
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             asm_buffer_load_b128(r[h], ok ? (uint32_t)(((size_t)m * N + (nc << 7) + h * 32 + fq * 8) * 2) : kOob, rres);
     };
-    u32x4 xq[NK * 2]; // the activation tile of this wave as B fragments: K slice q = channels q*32 + fq*8 .. +7 of pixel `frow`
+    u32x4 xq[NKT * 2]; // the activation tile of this wave as B fragments: K slice q = channels q*32 + fq*8 .. +7 of pixel `frow`
     auto issue_x = [&](int mt) {
         const int m = mt * BM + wave * 16 + frow;
         const bool ok = mt < tiles_m && m < M;
 #pragma unroll
         for (int q = 0; q < NK * 2; ++q) asm_buffer_load_b128(xq[q], ok ? (uint32_t)(((size_t)m * K + q * 32 + fq * 8) * 2) : kOob, rxs);
+        if (NK2) { // the shortcut's source pixel: (b, stride2 * ho, stride2 * wo) of x2
+            const int HoWo = p.Ho * p.Wo, mm = ok ? m : 0, b = mm / HoWo, rem = mm - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const uint32_t base = (uint32_t)(((((size_t)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + fq * 8) * 2);
+#pragma unroll
+            for (int q = 0; q < NK2 * 2; ++q) asm_buffer_load_b128(xq[NK * 2 + q], ok ? base + (uint32_t)(q * 64) : kOob, rxs2);
+        }
     };
 
-    u32x4 resA[4], resB[4];
+    u32x4 resA[4] = {}, resB[4] = {};
     issue_x(blockIdx.x);
     issue_res(resA, blockIdx.x, 0);
 #pragma unroll
@@ -934,7 +945,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < NK; ++kt) { // conv3 steps: all 128 rows of the slot against this wave's 16 pixels
+            for (int kt = 0; kt < NKT; ++kt) { // conv3 (+ shortcut) steps: all 128 rows of the slot against this wave's 16 pixels
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue_w();
                 const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
@@ -953,7 +964,8 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             // the next tile's activation fragments may be requested as soon as this tile's last conv3 step has read them
             if (last_chunk) issue_x(mt + (int)gridDim.x);
             // ---- the one drain of the chunk: residual of this chunk, W1 steps of this chunk, stores of the previous one ----
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            if (HAS_RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (!last_chunk) issue_res(nxt, mt, nc + 1);
             else issue_res(nxt, mt + (int)gridDim.x, 0);
@@ -973,10 +985,12 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
                     v[k] = acc[2 * h][k] + bias[k];
                     v[4 + k] = acc[2 * h + 1][k] + bias[4 + k];
                 }
+                if (HAS_RES) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
-                    v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] += bf16_bits_to_f32(rv[k] & 0xffffu);
+                        v[2 * k + 1] += bf16_bits_to_f32(rv[k] >> 16);
+                    }
                 }
                 uint2 alo, ahi;
                 if (ACT_OUT) {
@@ -1126,15 +1140,15 @@ template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hi
     const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
     return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
 }
-template <int NK, int N1B, bool ACT_OUT> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
     const int ncu = persistent_cus(p.co_running, true);
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    const size_t lds_need = (size_t)(NK + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
-    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT>>(grid, lds_need, s, p);
+    const size_t lds_need = (size_t)(NK + NK2 + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
+    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2783,11 +2797,14 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         const int N1 = p.n1;
         // RFD_PW_PAIR=1: pw_pair_kernel for every pair (A/B against pw_b2b_kernel); default: stage 3 only
         static const int pair_all = [] { const char *e = getenv("RFD_PW_PAIR"); return e ? atoi(e) : 0; }();
-        const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && shape && p.Cin2 == 0 && !p.in_scale &&
-                          p.res && !p.res_up2 && !p.res_post && !p.relu && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
+        // the first unit of stage 2: conv3 128 -> 512 with the 1x1 stride-2 shortcut 256 -> 512 as second K segment, no residual
+        const bool u1 = !act_out && p.Cin == 128 && p.Cin2 == 256 && p.stride2 == 2 && p.Cout == 512 && p.n1 == 128 && !p.res && p.y && !p.y2 && p.ldy == p.Cout && p.bias2;
+        const bool fuse = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && (u1 || (shape && p.Cin2 == 0 && p.res)) && !p.in_scale &&
+                          !p.res_up2 && !p.res_post && !p.relu && !p.yf && p.ldx == p.Cin && p.x_coff == 0 &&
                           p.y_coff == 0 && p.y_split >= p.Cout && p.n_valid >= p.Cout &&
                           (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
         if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) {
+            if (u1) return launch_pw_pair<2, 1, false, 4>(p, s);
             if (s3) return p.n1 == 256 ? launch_pw_pair<4, 2, false>(p, s) : RFD_ERR_INVALID_ARG;
             if (b23) return launch_pw_pair<2, 2, true>(p, s);
             if (pair_all) return act_out ? launch_pw_pair<1, 1, true>(p, s) : launch_pw_pair<2, 1, false>(p, s);

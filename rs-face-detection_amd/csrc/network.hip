@@ -131,7 +131,7 @@ void Graph::build_r50()
             if (!dim_match) { ops[o3].in2 = x_act; ops[o3].layer2 = ls; }
             // stage 2 (round 3): the same pairing for the dim-match units -- pw_b2b_kernel, or two launches where it does not pay
             // (RFD_B2B_STAGES=1 keeps it to stage 1: A/B knob)
-            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 5; }(); // 1: stage 1 only; 2: + stage 2's middle units; 3: + stage 1 -> 2; 4: + stage 3's middle units; 5: + stage 2 -> 3
+            static const int b2b_stages = [] { const char *e = getenv("RFD_B2B_STAGES"); return e ? atoi(e) : 6; }(); // 1: stage 1 only; 2: + stage 2's middle units; 3: + stage 1 -> 2; 4: + stage 3's middle units; 5: + stage 2 -> 3; 6: + stage 2's first unit
             if ((s == 0 && last && b2b_stages >= 3) || (s == 1 && last && b2b_stages >= 5)) {
                 // the last unit of stage 1 with stage 2's first conv1 (256 -> 128 at 160 x 160, on the stage output): pw_b2b_kernel;
                 // the last unit of stage 2 with stage 3's first conv1 (512 -> 256 at 80 x 80): pw_pair_kernel
@@ -140,7 +140,8 @@ void Graph::build_r50()
                 b2b_t1 = add_tensor(mids[s + 1], ho, wo);
                 ops[o3].kind = OP_B2B; ops[o3].layer_b = l1n; ops[o3].out_b = b2b_t1;
             }
-            if ((s == 0 || (s == 1 && b2b_stages >= 2 && dim_match && fuse_act) || (s == 2 && b2b_stages >= 4 && dim_match && fuse_act)) && !last) {
+            if ((s == 0 || (s == 1 && b2b_stages >= 2 && dim_match && fuse_act) || (s == 2 && b2b_stages >= 4 && dim_match && fuse_act) ||
+                 (s == 1 && b2b_stages >= 6 && !dim_match && fuse_act)) && !last) {
                 // stage 1: conv3 of this unit and conv1 of the NEXT unit run back to back in one kernel; the
                 // activated 256-channel tile stays in LDS (conv_b2b_s1_kernel)
                 snprintf(nm, sizeof nm, "stage%d_unit%d_conv1", s + 1, u + 2);

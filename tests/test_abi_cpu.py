@@ -39,9 +39,9 @@ def test_graph_matches_survey_appendix_b(rfd):
     fused_n = [o for o in g.ops if o.layer_n2 >= 0]    # 6 SSH sibling pairs run as one GEMM along N
     b2b = [o for o in g.ops if o.kind == 6]             # conv3 + next conv1 back to back (stage 1; since round 3 stage 2's dim-match units)
     assert len(convs) + 2 * len(heads) + len(fused_sc) + len(fused_n) + len(b2b) == 82  # 9 head convs = 3 fused N=32 GEMMs
-    assert len(b2b) == 10
+    assert len(b2b) == 11
     assert sorted(g.layers[o.layer].name.decode() for o in b2b) == ["stage1_unit1_conv3", "stage1_unit2_conv3", "stage1_unit3_conv3",
-                                                                   "stage2_unit2_conv3", "stage2_unit3_conv3", "stage2_unit4_conv3", "stage3_unit2_conv3",
+                                                                   "stage2_unit1_conv3", "stage2_unit2_conv3", "stage2_unit3_conv3", "stage2_unit4_conv3", "stage3_unit2_conv3",
                                                                    "stage3_unit3_conv3", "stage3_unit4_conv3", "stage3_unit5_conv3"]
     assert len(fused_n) == 6
     assert len(fused_sc) == 4 and g.num_layers == 76
