@@ -844,10 +844,15 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 // ------------------------------------------------------------------------------------------------
 // NK2 > 0: the first unit of a stage -- the 1x1 stride-2 shortcut conv rides in the same GEMM as a second K segment (NK2 more K
 // steps whose activation fragments are gathered from x2 at (2 ho, 2 wo)), its bias is added to conv3's, and there is no residual.
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0>
+// RESIDENT (NCR = number of chunks, > 0): both filter banks fit LDS (stage 1 -> 2 boundary: 32 + 64 KiB) and are staged ONCE, in
+// stream order; after that there is no weight traffic, no ring and therefore no barrier: every wave is an independent pipeline over
+// its 16 pixels.  These kernels are bound by the bytes a CU can pull through its vector-memory path (~25 GB/s per CU, L2-served
+// weight steps included: 272 KiB per tile streaming, 176 KiB resident).
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0>
 __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
 {
-    constexpr int BM = 128, NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = S + 1, N1 = 128 * N1B;
+    constexpr bool RESIDENT = NCR > 0;
+    constexpr int BM = 128, NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : S + 1, N1 = 128 * N1B;
     constexpr bool HAS_RES = NK2 == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Ws = reinterpret_cast<bf16_t *>(smem);                    // [WSLOTS][128*64]
@@ -926,10 +931,17 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     };
 
     u32x4 resA[4] = {}, resB[4] = {};
+    if (RESIDENT) { // the whole of both filter banks, once: NCR chunks x S steps fill the NCR * S slots in consumption order
+        for (int i = 0; i < WSLOTS; ++i) issue_w();
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
     issue_x(blockIdx.x);
     issue_res(resA, blockIdx.x, 0);
+    if (!RESIDENT) {
 #pragma unroll
-    for (int i = 0; i < S; ++i) issue_w(); // the first chunk's steps
+        for (int i = 0; i < S; ++i) issue_w(); // the first chunk's steps
+    }
     int cslot = 0;
     const int arow = frow * 64; // A fragment of row block i: row i*16 + frow; 16-byte slot (kk*4 + fq) ^ (row & 7), row & 7 = frow & 7
 
@@ -946,8 +958,10 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) { // conv3 (+ shortcut) steps: all 128 rows of the slot against this wave's 16 pixels
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                issue_w();
+                if (!RESIDENT) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    issue_w();
+                }
                 const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
                 cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
 #pragma unroll
@@ -1017,8 +1031,10 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int k1 = 0; k1 < 2; ++k1)       // conv1: the chunk's 64-channel half k1 ...
 #pragma unroll
                 for (int r1 = 0; r1 < N1B; ++r1) { // ... against the 128-row block r1 of W1 (one slot-step)
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    issue_w();
+                    if (!RESIDENT) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        issue_w();
+                    }
                     const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
                     cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
 #pragma unroll
@@ -1140,15 +1156,17 @@ template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hi
     const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
     return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
 }
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
 {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
     const int ncu = persistent_cus(p.co_running, true);
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
-    const size_t lds_need = (size_t)(NK + NK2 + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
-    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2>>(grid, lds_need, s, p);
+    const size_t slots = NCR ? (size_t)NCR * (NK + NK2 + 2 * N1B) : (size_t)(NK + NK2 + 2 * N1B + 1);
+    const size_t lds_need = slots * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
+    if (NCR && p.Cout != NCR * 128) { set_error("pw_pair: resident form instantiated for %d output channels", NCR * 128); return RFD_ERR_INVALID_ARG; }
+    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2, NCR>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2807,7 +2825,9 @@ int launch_conv(const ConvParams &p, hipStream_t s)
             if (u1) return launch_pw_pair<2, 1, false, 4>(p, s);
             if (s3) return p.n1 == 256 ? launch_pw_pair<4, 2, false>(p, s) : RFD_ERR_INVALID_ARG;
             if (b23) return launch_pw_pair<2, 2, true>(p, s);
-            if (pair_all) return act_out ? launch_pw_pair<1, 1, true>(p, s) : launch_pw_pair<2, 1, false>(p, s);
+            // the stage 1 -> 2 boundary: both filter banks (96 KiB) resident in LDS, barrier-free (RFD_PW_PAIR=2: the streaming pw_b2b form)
+            if (act_out && pair_all != 2) return launch_pw_pair<1, 1, true, 0, 2>(p, s);
+            if (pair_all == 1) return act_out ? launch_pw_pair<1, 1, true>(p, s) : launch_pw_pair<2, 1, false>(p, s);
             return act_out ? launch_pw_b2b<1, true>(p, s) : launch_pw_b2b<2, false>(p, s);
         }
         ConvParams a = p;
