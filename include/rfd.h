@@ -341,7 +341,8 @@ RFD_API int rfd_get_op_profile(rfd_ctx *ctx, float *ms, int cap);
  *      op list [first_op, last_op] (last_op < 0: to the end), so every op can be checked in isolation. */
 RFD_API int rfd_debug_tensor_io(rfd_ctx *ctx, int tensor_id, int n, void *host, int write);
 RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
-/* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal */
+/* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal, 17 = the
+ * wave-specialised ring form wherever the layer shape allows (the full list: launch_conv in csrc/kernels_conv.hip) */
 RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
 /* execution structure of the network pass: side streams for independent chains on/off; batch split into
  * clamp(n / split_min_part, 1, split_max_parts) contiguous parts that run as independent chains on their own streams

@@ -231,6 +231,8 @@ struct rfd_ctx {
     {
         if (net_created) return RFD_OK;
         RFD_TRY(net.create(cfg.backbone, cfg.image_w, cfg.image_h, cfg.max_batch_size, cfg.precision));
+        // the ring convolutions' bounded spins report into the same device word as the chunked NMS (check_nms_flag)
+        net.d_fail = (int *)nms_state.p + (size_t)cfg.max_batch_size * kNmsChunks * 2;
         net_created = true;
         return RFD_OK;
     }
@@ -361,7 +363,8 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
     RFD_TRY(launch_nms(np, n, c->stream));
     RFD_HIP(hipEventRecord(c->ev[6], c->stream));
     // the device word is sticky (the kernel only ever sets it), so a later call's copy cannot hide an earlier give-up
-    if (np.spin_fail) RFD_HIP(hipMemcpyAsync(c->h_nms_flag, np.spin_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // (copied whether or not the chunked kernel ran: the ring convolutions of the network pass report into the same word)
+    RFD_HIP(hipMemcpyAsync(c->h_nms_flag, (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return RFD_OK;
 }
 
@@ -376,8 +379,9 @@ int check_nms_flag(rfd_ctx *c)
     int *flag = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
     RFD_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
-    set_error("chunked NMS: a workgroup timed out waiting for its predecessor chunk; the detections of the batches since the "
-              "last synchronisation are invalid (re-submit them; RFD_NMS_CHUNKED=0 selects the one-workgroup-per-image kernel)");
+    set_error("a device-side bounded wait gave up (chunked NMS: a workgroup waiting for its predecessor chunk; ring convolution: a "
+              "wave waiting for a ring slot); the detections of the batches since the last synchronisation are invalid "
+              "(re-submit them; RFD_NMS_CHUNKED=0 selects the one-workgroup-per-image NMS kernel, RFD_CONV_RING=0 the barrier-per-step convolutions)");
     return RFD_ERR_HIP;
 }
 
@@ -840,7 +844,7 @@ int rfd_debug_tensor_io(rfd_ctx *c, int tensor_id, int n, void *host, int write)
 }
 int rfd_debug_set_conv_tile(rfd_ctx *c, int tile)
 {
-    RFD_CHECK_ARG(c && tile >= 0 && tile <= 15, "bad argument");
+    RFD_CHECK_ARG(c && tile >= 0 && tile <= 31, "bad argument");
     RFD_TRY(c->ensure_network());
     c->net.force_tile = tile;
     return RFD_OK;
@@ -876,9 +880,10 @@ int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
     RFD_TRY(c->ensure_network());
     c->ov_last_n = -1;
     RFD_TRY(c->net.run(n, c->stream, first_op, last_op));
+    RFD_HIP(hipMemcpyAsync(c->h_nms_flag, c->net.d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RFD_HIP(hipStreamSynchronize(c->stream));
     if (c->net.profiling) RFD_TRY(c->net.collect_profile());
-    return RFD_OK;
+    return check_nms_flag(c);
 }
 
 // ---- weights ----
@@ -1291,6 +1296,7 @@ int rfd_forward(rfd_ctx *c, const float *tensor, int n, float *const heads[9])
     RFD_TRY(launch_tensor_to_nhwc4((const float *)c->scratch[1].p, (bf16_t *)c->net.tensor_ptr(c->net.g.input), n,
                                    c->cfg.image_h, c->cfg.image_w, c->stream));
     RFD_TRY(c->net.run(n, c->stream));
+    RFD_HIP(hipMemcpyAsync(c->h_nms_flag, c->net.d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     for (int l = 0; l < kNumLevels; ++l) {
         const size_t hw = (size_t)c->fh[l] * c->fw[l];
         RFD_TRY(c->scratch[2].reserve(n * hw * 32 * sizeof(float)));
@@ -1304,7 +1310,7 @@ int rfd_forward(rfd_ctx *c, const float *tensor, int n, float *const heads[9])
         RFD_HIP(hipStreamSynchronize(c->stream)); // scratch[2] is reused by the next level
     }
     if (c->net.profiling) RFD_TRY(c->net.collect_profile());
-    return RFD_OK;
+    return check_nms_flag(c);
 }
 
 int rfd_decode_nms(rfd_ctx *c, const float *const heads[9], int n, const float *det_scale, rfd_dets *out,

@@ -146,8 +146,12 @@ struct ConvParams {
     const float *bias1;
     bf16_t *t1;
     int n1;               // conv1's output channels (128 or 256)
+    int *fail;            // device word a kernel with bounded spin waits (kernels_ring.hip) sets when a wave gives up, or null
 };
 int launch_conv(const ConvParams &p, hipStream_t s);
+// wave-specialised loader / consumer ring form of the 128 x 128 implicit-GEMM tile (kernels_ring.hip)
+bool conv_ring_supports(const ConvParams &p, bool *kx3);
+int launch_conv_ring(const ConvParams &p, hipStream_t s);
 // entry i of the list of persistent kernels (name prefix, dynamic LDS every launch of it requests); returns the list length
 int persistent_kernel_table(int i, const char **name, size_t *lds_bytes);
 // ---- f32 parity mode (kernels_f32.hip): ConvParams with f32 tensors and weights; same field meanings ----

@@ -83,6 +83,7 @@ struct Network {
     bf16_t *d_w = nullptr;
     float *d_b = nullptr;
     bf16_t *d_zero = nullptr;
+    int *d_fail = nullptr;    // device fault word of the owning context (bounded spins of the ring convolutions), or null
     std::vector<void *> d_buffers;
     bool profiling = false;
     int force_tile = 0; // test hook: 0 heuristic, 1 = 128-row tiles only, 2 = 256x128 wherever Cout % 128 == 0

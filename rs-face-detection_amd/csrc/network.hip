@@ -801,6 +801,7 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             p.zero = d_zero;
             p.force_tile = force_tile;
             p.co_running = co_running;
+            p.fail = d_fail;
             p.res = o.res >= 0 ? (const bf16_t *)tensor_ptr(o.res, batch_off) : nullptr;
             if (o.layer2 >= 0) {
                 const Layer &L2 = g.layers[o.layer2];

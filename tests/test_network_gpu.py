@@ -47,9 +47,9 @@ def _check_close(got, want, what):
     return float(np.mean(got == want))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 6, 17])
 def test_every_op_in_isolation(rfd, net, tile):
-    """tile 0: the production heuristic (merged-kx 3x3 kernel, asymmetric rings, persistent kernels where the problem is
+    """tile 17: the wave-specialised ring (kernels_ring.hip) wherever the layer shape allows; tile 0: the production heuristic (merged-kx 3x3 kernel, asymmetric rings, persistent kernels where the problem is
     large enough); tile 6: the same with the persistent kernels (pw_stream, conv3x3_c64) forced at this small batch; tile 1: every conv on the generic 128-row, 2-slot tiles; tile 2: the 256x128, 3-slot-ring tile wherever
     Cout % 128 == 0 (the heuristic picks between them by grid size at run time)."""
     det, g, ref = net

@@ -228,19 +228,118 @@ def ds_read_b128_under_partial_exec(ins):
     return bad
 
 
-def report(objs=("kernels_pre", "kernels_post", "kernels_conv", "kernels_f32")):
+_VMCNT = re.compile(r"vmcnt\((\d+)\)")
+
+
+def _is_store(m):
+    return m.startswith(("buffer_store", "global_store", "flat_store", "scratch_store", "buffer_atomic", "global_atomic", "flat_atomic"))
+
+
+def _publishes(ins, i, addr_idx, depth=24):
+    """does the code right behind instruction i hand data to other waves (an LDS add / write or a barrier) before the next
+    wait on the vector-memory counter?  Follows fall-through and branch targets for a few instructions."""
+    seen, work = set(), [(i + 1, depth)]
+    while work:
+        j, d = work.pop()
+        while j < len(ins) and d > 0 and j not in seen:
+            seen.add(j)
+            a, m, o, t = ins[j]
+            if m == "s_barrier" or m.startswith(("ds_add", "ds_write")):
+                return True
+            if m == "s_waitcnt" and _VMCNT.search(o):
+                break
+            if m == "s_endpgm":
+                break
+            if t is not None and t in addr_idx:
+                work.append((addr_idx[t], d - 1))
+                if m == "s_branch":
+                    break
+            j += 1
+            d -= 1
+    return False
+
+
+def counted_vmcnt_with_store_in_flight(ins):
+    """addresses of PUBLISHING counted waits -- `s_waitcnt vmcnt(N > 0)` followed by an LDS add / write or a barrier, i.e. the
+    wait that tells other waves "this LDS-DMA tile has landed" -- that may execute while a vector store (or atomic) of the same
+    wave is outstanding.
+
+    "All but my N youngest operations are done" publishes the right tile only if the N youngest are the later DMAs.  The
+    persistent kernels of round 2 had output stores queued among them and saw stale tiles; they drain (vmcnt(0)) ever since.
+    The ring kernels (kernels_ring.hip) keep counted waits, in loader waves that never store -- this check holds them to it.
+    Forward may-analysis: state = (dma pending, store pending); an s_waitcnt with vmcnt(0) clears both.  Waits hipcc places in
+    front of an epilogue's register uses are not publishing waits and are left alone."""
+    addr_idx = {a: i for i, (a, m, o, t) in enumerate(ins)}
+
+    def tr(st, instr, _):
+        dma, store = st
+        a, m, o, t = instr
+        if m.startswith("buffer_load") and re.search(r"\blds\b", o):
+            dma = True
+        elif _is_store(m):
+            store = True
+        elif m == "s_waitcnt":
+            v = _VMCNT.search(o)
+            if v and int(v.group(1)) == 0:
+                dma, store = False, False
+        return (dma, store)
+    blocks, entry = _dataflow(ins, tr, (False, False), lambda x, y: (x[0] or y[0], x[1] or y[1]))
+    bad = []
+    for (s, e), st in zip(blocks, entry):
+        if st is None:
+            continue
+        for i in range(s, e):
+            a, m, o, t = ins[i]
+            if m == "s_waitcnt":
+                v = _VMCNT.search(o)
+                if v and int(v.group(1)) > 0 and st[0] and st[1] and _publishes(ins, i, addr_idx):
+                    bad.append(hex(a))
+            st = tr(st, ins[i], None)
+    return bad
+
+
+def counted_vmcnt_waits(ins):
+    """addresses of every PUBLISHING `s_waitcnt vmcnt(N > 0)` reached with an LDS-DMA possibly outstanding (the waits the rule is about)"""
+    def tr(st, instr, _):
+        a, m, o, t = instr
+        if m.startswith("buffer_load") and re.search(r"\blds\b", o):
+            return True
+        if m == "s_waitcnt":
+            v = _VMCNT.search(o)
+            if v and int(v.group(1)) == 0:
+                return False
+        return st
+    addr_idx = {a: i for i, (a, m, o, t) in enumerate(ins)}
+    blocks, entry = _dataflow(ins, tr, False, lambda x, y: x or y)
+    out = []
+    for (s, e), st in zip(blocks, entry):
+        if st is None:
+            continue
+        for i in range(s, e):
+            a, m, o, t = ins[i]
+            if m == "s_waitcnt" and st:
+                v = _VMCNT.search(o)
+                if v and int(v.group(1)) > 0 and _publishes(ins, i, addr_idx):
+                    out.append(hex(a))
+            st = tr(st, ins[i], None)
+    return out
+
+
+def report(objs=("kernels_pre", "kernels_post", "kernels_conv", "kernels_ring", "kernels_f32")):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         for f in objs:
             ks = disassemble(os.path.join(BUILD, f + ".o"), tmp)
             for name, ins in ks.items():
                 rows.append((f, name, len(ins), uses_lds_dma(ins), len(has_instr(ins, "ds_read_b128")),
-                             pending_lds_reads_at_barriers(ins), ds_read_b128_under_partial_exec(ins)))
+                             pending_lds_reads_at_barriers(ins), ds_read_b128_under_partial_exec(ins),
+                             counted_vmcnt_with_store_in_flight(ins), counted_vmcnt_waits(ins)))
     return rows
 
 
 if __name__ == "__main__":
-    for f, name, n, dma, nb128, bar, ex in report():
-        flag = ("  BARRIER-WITH-PENDING-LDS-READ " + ",".join(bar) if dma and bar else "") + ("  B128-UNDER-PARTIAL-EXEC " + ",".join(ex) if ex else "")
-        print("%-13s %-90s %6d instr  lds-dma=%d  ds_read_b128=%d%s" % (f, name[:90], n, dma, nb128, flag))
+    for f, name, n, dma, nb128, bar, ex, cnt_bad, cnt in report():
+        flag = ("  BARRIER-WITH-PENDING-LDS-READ " + ",".join(bar) if dma and bar else "") + ("  B128-UNDER-PARTIAL-EXEC " + ",".join(ex) if ex else "") + \
+               ("  COUNTED-VMCNT-WITH-STORE-IN-FLIGHT " + ",".join(cnt_bad) if cnt_bad else "")
+        print("%-13s %-90s %6d instr  lds-dma=%d  ds_read_b128=%d  counted-vmcnt-behind-dma=%d%s" % (f, name[:90], n, dma, nb128, len(cnt), flag))
     sys.exit(0)
