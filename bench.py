@@ -303,20 +303,11 @@ def main():
         sus_s = float(os.environ.get("RFD_BENCH_SUSTAIN_S", "3.0"))
         chunk = max(args.steps, 10)
         fence()
-        s0 = time.perf_counter()
-        ssteps = 0
-        while True:
-            for _ in range(chunk):
-                step()
-            ssteps += chunk
-            det.sync()
-            torch.cuda.synchronize()
-            s1 = time.perf_counter()
-            if s1 - s0 >= sus_s:
-                break
+        # (the stop decision is collective -- parallel.run_for_at_least: every step() of a multi-rank job holds an all-gather)
+        sus_elapsed, ssteps = parallel.run_for_at_least(step, lambda: (det.sync(), torch.cuda.synchronize()), sus_s, chunk, world, dev)
         if world > 1:
             dist.barrier()
-        sus = torch.tensor([s1 - s0, float(ssteps)], dtype=torch.float64, device=dev)
+        sus = torch.tensor([sus_elapsed, float(ssteps)], dtype=torch.float64, device=dev)
         if world > 1:  # whole-job figure: all ranks' images over the slowest rank's window
             t_max = sus[:1].clone(); dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
             n_sum = sus[1:].clone(); dist.all_reduce(n_sum, op=dist.ReduceOp.SUM)

@@ -41,6 +41,8 @@ def lib():
         L.rfd_oracle_anchors_fpn.argtypes = [_f32p]
         L.rfd_oracle_anchor_plane.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, C.c_int, _f32p]
         L.rfd_oracle_bbox_pred.argtypes = [_f32p, _f32p, C.c_int, _f32p]
+        L.rfd_oracle_expf_restated.argtypes = [_f32p, C.c_int, _f32p]
+        L.rfd_oracle_expf_libm.argtypes = [_f32p, C.c_int, _f32p]
         L.rfd_oracle_landmark_pred.argtypes = [_f32p, _f32p, C.c_int, _f32p]
         L.rfd_oracle_clip_boxes.argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
         L.rfd_oracle_argsort_desc.argtypes = [_f32p, C.c_int, _i32p]
@@ -90,6 +92,14 @@ def anchor_plane(height, width, stride, base):
     base = np.ascontiguousarray(base, np.float32)
     out = np.zeros((height, width, base.shape[0], 4), np.float32)
     lib().rfd_oracle_anchor_plane(height, width, stride, base, base.shape[0], out)
+    return out
+
+
+def expf(x, restated=False):
+    """the host libm's expf (what Rust's f32::exp calls), or the device kernel's restatement of it evaluated on the CPU"""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    out = np.empty_like(x)
+    (lib().rfd_oracle_expf_restated if restated else lib().rfd_oracle_expf_libm)(x, x.size, out)
     return out
 
 

@@ -111,6 +111,45 @@ RFD_API void rfd_oracle_anchor_plane(int height, int width, int stride, const fl
  * clip: src/processing/bbox_transform.rs:27-45
  * ------------------------------------------------------------------------------------------ */
 
+/* f32::exp (face_detection.rs:534-535) is the platform libm's expf; every oracle function calls exactly that.  The two entry
+ * points below exist to PIN the device's restatement of it (csrc/kernels_post.hip: exp_cr) without a GPU: `restated` is the same
+ * operation sequence as the device code (glibc >= 2.27 e_expf.c: exp2f table algorithm, r = fma(x, 32/ln2, -k): the build glibc's
+ * ifunc selects on x86-64 CPUs with FMA), `libm` is the host's expf.  tests/test_oracle_cpu.py compares them on ~10^7 inputs. */
+static const unsigned long long k_exp2f_tab[32] = {0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+RFD_API void rfd_oracle_expf_restated(const float *x, int n, float *out)
+{
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    for (int i = 0; i < n; ++i) {
+        uint32_t u;
+        memcpy(&u, &x[i], 4);
+        const uint32_t abstop = (u >> 20) & 0x7ff;
+        if (abstop >= 0x42b) { /* |x| >= 88 or NaN */
+            if (u == 0xff800000u) { out[i] = 0.0f; continue; }
+            if (abstop >= 0x7f8) { out[i] = x[i] + x[i]; continue; }
+            if (x[i] > 0x1.62e42ep6f) { out[i] = INFINITY; continue; }
+            if (x[i] < -0x1.9fe368p6f) { out[i] = 0.0f; continue; }
+        }
+        const double xd = (double)x[i];
+        double kd = fma(InvLn2N, xd, Shift);
+        unsigned long long ki;
+        memcpy(&ki, &kd, 8);
+        kd -= Shift;
+        const double r = fma(InvLn2N, xd, -kd);
+        const unsigned long long t = k_exp2f_tab[ki & 31] + (ki << 47);
+        double sc;
+        memcpy(&sc, &t, 8);
+        const double z = fma(C0, r, C1), r2 = r * r;
+        double y = fma(C2, r, 1.0);
+        y = fma(z, r2, y);
+        out[i] = (float)(y * sc);
+    }
+}
+RFD_API void rfd_oracle_expf_libm(const float *x, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = expf(x[i]);
+}
+
 /* bbox_pred, face_detection.rs:516-549 (first 4 columns). boxes,deltas,out: [n][4]. */
 RFD_API void rfd_oracle_bbox_pred(const float *boxes, const float *deltas, int n, float *out)
 {

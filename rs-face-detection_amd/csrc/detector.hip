@@ -249,8 +249,9 @@ int ctx_alloc(rfd_ctx *c)
     RFD_TRY(c->sorted_keys.reserve(B * NA * sizeof(uint64_t)));
     RFD_TRY(c->sorted_boxes.reserve(B * NA * sizeof(float4)));
     RFD_TRY(c->nms_kept.reserve(B * NA * sizeof(float4)));
-    RFD_TRY(c->nms_state.reserve((B * kNmsChunks * 2 + 1) * sizeof(int)));
-    RFD_HIP(hipMemset(c->nms_state.p, 0, (B * kNmsChunks * 2 + 1) * sizeof(int)));
+    // per-chunk progress words | fault word (+ pad) | the chunk-ticket word (8-byte aligned)
+    RFD_TRY(c->nms_state.reserve((B * kNmsChunks * 2 + 4) * sizeof(int)));
+    RFD_HIP(hipMemset(c->nms_state.p, 0, (B * kNmsChunks * 2 + 4) * sizeof(int)));
     RFD_HIP(hipDeviceSynchronize()); // the fill runs on the NULL stream, which the context's non-blocking stream is not ordered with
     RFD_TRY(c->count.reserve(B * sizeof(int)));
     RFD_TRY(c->det_scale.reserve(B * sizeof(float)));
@@ -357,6 +358,7 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
         np.kept_boxes = (float4 *)c->nms_kept.p;
         np.chunk_state = (int *)c->nms_state.p;
         np.spin_fail = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
+        np.ticket = (unsigned long long *)(np.spin_fail + 2);
         c->nms_epoch = c->nms_epoch == 0x7fffffff ? 1 : c->nms_epoch + 1;
         np.epoch = c->nms_epoch;
     }

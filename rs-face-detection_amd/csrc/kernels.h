@@ -66,6 +66,7 @@ struct NmsParams {
     float4 *kept_boxes;          // [n][total_anchors] scratch: the kept boxes of an image in score order, chunk after chunk
     int *chunk_state;            // [n][kNmsChunks][2]: {kept count, epoch of the launch that published it}; zero-initialised once
     int *spin_fail;              // set to 1 if a chunk gave up waiting for its predecessor (bounded spin; never expected)
+    unsigned long long *ticket;  // {epoch : 32 | next chunk id : 32}: workgroups draw their (image, chunk) in the order they start
     int epoch;                   // > 0, different for every launch that uses chunk_state
 };
 constexpr int kNmsChunks = 4;

@@ -817,6 +817,11 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
         for (int i = 0; i < 8 * N1B; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the tile's activation fragments (requested during the previous tile's last chunk, or before the loop) and everything older
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        // ... and xq[] is only defined from here on: tied to the wait as cur[] is below, so that no copy of a fragment register
+        // hipcc might make (a phi across the back edge, a spill-free re-allocation) can be taken before the loads have landed
+        // (volatile asm statements keep their order; round-3 advisor finding)
+#pragma unroll
+        for (int q = 0; q < NKT * 2; ++q) asm volatile("" : "+v"(xq[q]));
         auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4], bool last_chunk) __attribute__((always_inline)) {
             f32x4 acc[8];
 #pragma unroll
@@ -2667,6 +2672,19 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX> static int launch_c
 
 int launch_conv(const ConvParams &p, hipStream_t s)
 {
+    // every kernel addresses its tensors through 32-bit buffer descriptors and offsets: inputs, outputs (M x Cout, M x ldy) and,
+    // for a back-to-back pair, conv1's output (M x n1) must each stay below 4 GiB -- checked before ANY path is chosen
+    // (round-3 advisor finding: the pair branch used to return before the guard; B >= 328 at the stage 1 -> 2 boundary wrapped)
+    {
+        const size_t Mo = (size_t)p.B * p.Ho * p.Wo, lim = 0xfffffff0ull;
+        const size_t in1 = (size_t)p.B * p.H * p.W * (p.ldx ? p.ldx : p.Cin) * 2, in2 = (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2;
+        const size_t out = Mo * (size_t)std::max(p.Cout, p.ldy) * (p.yf ? 4 : 2), out1 = p.w1 ? Mo * (size_t)p.n1 * 2 : 0;
+        if (in1 >= lim || in2 >= lim || out >= lim || out1 >= lim) {
+            set_error("conv: a tensor of %zu bytes exceeds the 4 GiB buffer-addressing limit; lower max_batch_size",
+                      std::max(std::max(in1, in2), std::max(out, out1)));
+            return RFD_ERR_CAPACITY;
+        }
+    }
     if (p.w1) {
         // conv3 of a dim-match unit + the next unit's conv1 (OP_B2B beyond stage 1).  One persistent kernel where pw_stream
         // itself would run (force_tile 7 / 1 / 2 and small batches: two launches; bit-identical either way).
@@ -2688,7 +2706,10 @@ int launch_conv(const ConvParams &p, hipStream_t s)
                           (p.force_tile == 6 || p.force_tile == 16 || (p.force_tile == 0 && M1 >= 128 * 128));
         if (fuse && (const char *)p.w1 > (const char *)p.w && (size_t)((const char *)p.w1 - (const char *)p.w) < (1u << 30)) {
             if (u1) return launch_pw_pair<2, 1, false, 4>(p, s);
-            if (s3) return p.n1 == 256 ? launch_pw_pair<4, 2, false>(p, s) : RFD_ERR_INVALID_ARG;
+            if (s3) {
+                if (p.n1 != 256) { set_error("conv pair: stage-3 form instantiated for n1 = 256, got %d", p.n1); return RFD_ERR_INVALID_ARG; }
+                return launch_pw_pair<4, 2, false>(p, s);
+            }
             if (b23) return launch_pw_pair<2, 2, true>(p, s);
             // the stage 1 -> 2 boundary: both filter banks (96 KiB) resident in LDS, barrier-free (RFD_PW_PAIR=2: the streaming pw_b2b form)
             if (act_out && pair_all != 2) return launch_pw_pair<1, 1, true, 0, 2>(p, s);

@@ -5,9 +5,14 @@
 // moves scores by ~3e-2 and boxes by up to a few pixels against an f32 evaluation of the same weights (tests/test_t2_gpu.py).
 // This file is the mode in which north_star's "identical kept-box index sets, coordinates within 1e-4" can be shown END TO END
 // against an independent f32 evaluation: the same graph (same fusions, same folded parameters, same op list) with f32 weights,
-// f32 activations and f32 FMA accumulation.  It is a correctness mode, not a fast path: plain LDS-tiled FMA kernels (64 x 64
-// outputs per workgroup, K step 16), no MFMA, no persistent kernels, one stream.  MI355X's f32 vector rate still runs the 32-frame
-// T2 set in well under a second.
+// f32 activations and -- since round 4 -- f64 ACCUMULATION with one rounding per convolution output: products of two f32 values are
+// exact in f64, so every conv output is the correctly rounded value of its exact sum (up to ~K * 2^-53, i.e. one output in ~10^5
+// lands on the other side of an f32 rounding boundary), whatever order the terms are added in.  Two f32 evaluations with
+// different summation orders differ by 1-3e-6 in the head tensors, which a 512-pixel anchor turns into 7e-4 px (round 3); two
+// f64-accumulating ones agree to the ulp, and north_star's 1e-4 becomes checkable end to end (tests/test_t2_gpu.py against
+// tests/torch_ref.py with acc64=True: f64 conv, .float() per layer).  Everything outside the sums is plain f32 in a fixed order.
+// It is a correctness mode, not a fast path: plain LDS-tiled FMA kernels (64 x 64 outputs per workgroup, K step 16), no MFMA,
+// no persistent kernels, one stream; ~60x slower than the bf16 path.
 //
 // Semantics follow the bf16 kernels op for op (kernels_conv.hip: conv_epilogue, stem_kernel, conv_b2b_s1_kernel) minus every
 // rounding of a stored tensor; the network input stays the bf16 NHWC4 tensor the preprocess kernel writes (raw 0..255: exact).
@@ -38,11 +43,11 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvF32Params p)
     const int ln = n0 + lrow;
     const bool ln_ok = ln < p.Cout;
 
-    float acc[4][4];
+    double acc[4][4]; // f64: the products are exact, the sum is rounded to f32 once (below)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
 
     for (int k0 = 0; k0 < K; k0 += kTK) {
         // ---- stage X[kTM][kTK] (im2col) and W[kTN][kTK]; Cin, Cin2 are multiples of 16, so a K step never straddles a tap ----
@@ -73,15 +78,15 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvF32Params p)
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kTK; ++kk) {
-            float a[4], b[4];
+            double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = Xs[kk][ty + 16 * i];
+            for (int i = 0; i < 4; ++i) a[i] = (double)Xs[kk][ty + 16 * i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Ws[kk][tx * 4 + j];
+            for (int j = 0; j < 4; ++j) b[j] = (double)Ws[kk][tx * 4 + j];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
         }
     }
 
@@ -100,7 +105,7 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvF32Params p)
         if (m >= M) continue;
         float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bias[j];
+        for (int j = 0; j < 4; ++j) v[j] = (float)acc[i][j] + bias[j]; // the one rounding of the sum, then f32 in a fixed order
         if (p.res) {
             size_t mr = (size_t)m;
             if (p.res_up2) {
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(256) conv0_f32_kernel(const bf16_t *__restrict
     const int n4 = (int)(t & 15) * 4;
     const long long m = t >> 4;
     const int b = (int)(m / ((long long)Ho * Wo)), rem = (int)(m - (long long)b * Ho * Wo), ho = rem / Wo, wo = rem - ho * Wo;
-    float acc[4] = {bias[n4], bias[n4 + 1], bias[n4 + 2], bias[n4 + 3]};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}; // f64 accumulation, one rounding (see the file header)
     for (int ky = 0; ky < 7; ++ky) {
         const int hi = 2 * ho - 3 + ky;
         if ((unsigned)hi >= (unsigned)H) continue;
@@ -166,13 +171,15 @@ __global__ void __launch_bounds__(256) conv0_f32_kernel(const bf16_t *__restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float *wr = w + ((size_t)(n4 + j) * 7 + ky) * 32 + kx * 4;
-                acc[j] = fmaf(c0, wr[0], acc[j]);
-                acc[j] = fmaf(c1, wr[1], acc[j]);
-                acc[j] = fmaf(c2, wr[2], acc[j]);
+                acc[j] = fma((double)c0, (double)wr[0], acc[j]);
+                acc[j] = fma((double)c1, (double)wr[1], acc[j]);
+                acc[j] = fma((double)c2, (double)wr[2], acc[j]);
             }
         }
     }
-    *reinterpret_cast<float4 *>(y + (size_t)m * 64 + n4) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    *reinterpret_cast<float4 *>(y + (size_t)m * 64 + n4) =
+        make_float4(fmaxf((float)acc[0] + bias[n4], 0.f), fmaxf((float)acc[1] + bias[n4 + 1], 0.f), fmaxf((float)acc[2] + bias[n4 + 2], 0.f),
+                    fmaxf((float)acc[3] + bias[n4 + 3], 0.f));
 }
 
 // 3x3 / stride 2 / pad 1 max pool, then per-channel affine + ReLU (the BN1+ReLU that opens the first unit); 4 channels per thread

@@ -16,10 +16,39 @@ namespace rfd {
 // decode
 // ------------------------------------------------------------------------------------------------
 
-// Correctly rounded f32 exp through f64 (matches glibc expf, which Rust's f32::exp calls, on all
-// but ~1e-8 of inputs): the 1e-4 coordinate tolerance and identical NMS decisions need the same
-// value the CPU computes, not a 1-ulp-off fast exp.
-__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+// f32 exp with the SAME value the reference's CPU computes: Rust's f32::exp (face_detection.rs:534-535) is the platform libm's
+// expf, and glibc's expf (>= 2.27, sysdeps/ieee754/flt-32/e_expf.c: Szabolcs Nagy's exp2f-table algorithm) is not correctly
+// rounded -- (float)exp((double)x), which rounds 1-3 shipped, differs from it on about one input in 10^4 by one ulp (round 3: one
+// coordinate of 14 752 in the dense-crowd test).  Restated here operation by operation in f64:
+//   z = x * (32 / ln 2);  k = nearest integer (ties to even: add and subtract 1.5 * 2^52);  r = z - k, computed with ONE rounding
+//   (fma) as the libm build for x86-64 CPUs with FMA does -- the ifunc variant every MI355X host selects; the generic build rounds
+//   z first and differs on ~3 inputs in 10^9 (oracle/ test: tests/test_oracle_cpu.py pins this restatement against the host's
+//   expf) --; 2^(k/32) from a 32-entry table of the fraction bits plus k's upper bits in the exponent field; degree-3 polynomial
+//   in r; one rounding to f32 at the end.  The table = bits(2^(i/32)) - (i << 47), derived with 60-digit arithmetic and equal to
+//   glibc's __exp2f_data.tab.  Special cases as e_expf.c: overflow -> +inf, underflow -> 0, NaN propagates.
+__device__ __constant__ unsigned long long kExp2fTab[32] = {0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+__device__ __forceinline__ float exp_cr(float x)
+{
+    const uint32_t abstop = (__float_as_uint(x) >> 20) & 0x7ff;
+    if (abstop >= (0x42b00000u >> 20)) { // |x| >= 88 or NaN
+        if (__float_as_uint(x) == 0xff800000u) return 0.0f;
+        if (abstop >= (0x7f800000u >> 20)) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);  // > log(2^128)
+        if (x < -0x1.9fe368p6f) return 0.0f;                          // < log(2^-150)
+    }
+    const double xd = (double)x;
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    double kd = __builtin_fma(InvLn2N, xd, Shift);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= Shift;
+    const double r = __builtin_fma(InvLn2N, xd, -kd);
+    const double sc = __longlong_as_double((long long)(kExp2fTab[ki & 31] + (ki << 47)));
+    const double z = __builtin_fma(C0, r, C1), r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    return (float)(y * sc);
+}
 
 __device__ __forceinline__ uint32_t score_sort_bits(float s)
 {
@@ -497,8 +526,8 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(NmsParams p)
 // The critical path is the sum of the chunks' INTERNAL loops, each over a quarter of the tiles with a quarter of the words
 // to scan per tile.  The result is the same greedy sequence: a candidate is tested against exactly the kept boxes that
 // precede it in score order, with the same f32 arithmetic.
-// Deadlock: a workgroup waits only for workgroups of LOWER blockIdx of the same launch, which the dispatcher has started
-// before it; the spin is bounded anyway (spin_fail).  Images with few candidates (<= kNmsChunkMin) are done by chunk 0 alone.
+// Deadlock: a workgroup waits only for workgroups that drew a LOWER ticket in the same launch, i.e. that are already running
+// (the chunk id is the ticket, not blockIdx); the spin is bounded anyway (spin_fail).  Images with few candidates (<= kNmsChunkMin) are done by chunk 0 alone.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNmsChunkMin = 2048;
 // bitmap words a wave owns in registers: a chunk has at most ceil(272 / kNmsChunks) = 68 tiles (17408 candidates), an unsplit
@@ -514,9 +543,27 @@ __global__ void __launch_bounds__(kNmsThreads) nms_chunked_kernel(NmsParams p)
     int *obase = reinterpret_cast<int *>(keptw + p.nwords_cap);               // [nwords_cap]
     uint64_t *kept_word = reinterpret_cast<uint64_t *>(obase + p.nwords_cap); // [2]
 
-    const int b = blockIdx.x / kNmsChunks, c = blockIdx.x % kNmsChunks;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Which (image, chunk) this workgroup is comes from a TICKET drawn when it starts to run, not from blockIdx: a chunk waits for
+    // the chunks of its image with lower tickets, and a lower ticket has been drawn, so its workgroup is running -- forward
+    // progress by construction, whatever order the dispatcher starts workgroups in (round-3 review; rounds 2-3 relied on
+    // "lower blockIdx starts first", which HIP does not promise).  The ticket word is {epoch : 32 | next : 32}; the first
+    // workgroup of a launch finds an older epoch and restarts the count (no memset between launches).
+    if (tid == 0) {
+        unsigned long long old = __hip_atomic_load(p.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), mine;
+        while (true) {
+            const bool fresh = (unsigned)(old >> 32) != (unsigned)p.epoch;
+            mine = fresh ? 0ull : (old & 0xffffffffull);
+            const unsigned long long upd = ((unsigned long long)(unsigned)p.epoch << 32) | (mine + 1ull);
+            if (__hip_atomic_compare_exchange_strong(p.ticket, &old, upd, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        reinterpret_cast<int *>(kept_word)[0] = (int)mine;
+    }
+    __syncthreads();
+    const int vb = __builtin_amdgcn_readfirstlane(reinterpret_cast<int *>(kept_word)[0]);
+    __syncthreads(); // kept_word is reused below
+    const int b = vb / kNmsChunks, c = vb % kNmsChunks;
     const int n = p.count[b];
     const int ntiles = (n + 63) >> 6;
     const bool split = n > kNmsChunkMin;
@@ -839,7 +886,7 @@ int launch_nms(NmsParams p, int n_images, hipStream_t s)
     static DynLdsOnce once_stream, once_reg;
     RFD_TRY(once_stream.ensure(reinterpret_cast<const void *>(nms_kernel<false>), 160 * 1024));
     RFD_TRY(once_reg.ensure(reinterpret_cast<const void *>(nms_kernel<true>), 160 * 1024));
-    if (reg && p.kept_boxes && p.chunk_state && p.spin_fail && p.epoch > 0 && p.presorted_n < 0)
+    if (reg && p.kept_boxes && p.chunk_state && p.spin_fail && p.ticket && p.epoch > 0 && p.presorted_n < 0)
         hipLaunchKernelGGL(nms_chunked_kernel, dim3(n_images * kNmsChunks), dim3(kNmsThreads), lds, s, p);
     else if (reg) hipLaunchKernelGGL(nms_kernel<true>, dim3(n_images), dim3(kNmsThreads), lds, s, p);
     else hipLaunchKernelGGL(nms_kernel<false>, dim3(n_images), dim3(kNmsThreads), lds, s, p);

@@ -48,11 +48,13 @@ __device__ __forceinline__ void resize_linear_px(const uint8_t *src, long long s
     const uint8_t *S1 = src + (long long)sy1 * stride;
     // The two taps of a row are the 6 consecutive bytes sx*3 .. sx*3+5 (sx1 = sx + 1): one unaligned 8-byte load per row instead
     // of six byte loads (round 3: the byte loads, not the arithmetic, held this kernel at 1.9 TB/s).  The wide load may touch
-    // the 2 bytes behind the second tap, so it is used only where those still lie inside the frame's own rows; the last pixels
+    // the 2 bytes behind the second tap, so it is used only where those still lie inside the frame's own extent; the last pixels
     // of the last row (and the clamped right edge, sx1 == sx) take the byte path.  Same integers either way.
     typedef uint64_t u64_unaligned __attribute__((aligned(1)));
     int t0[6], t1[6];
-    const long long o0 = (long long)sy0 * stride + sx * 3, o1 = (long long)sy1 * stride + sx * 3, lim = (long long)h * stride - 8;
+    // (the frame's real extent is (h-1) * stride + w * 3 bytes -- a caller's buffer with padded rows need not own the padding
+    //  behind its LAST row (an OpenCV ROI, an exactly-sized allocation); round-3 advisor finding)
+    const long long o0 = (long long)sy0 * stride + sx * 3, o1 = (long long)sy1 * stride + sx * 3, lim = (long long)(h - 1) * stride + (long long)w * 3 - 8;
     if (sx1 == sx + 1 && o0 <= lim && o1 <= lim) {
         const uint64_t q0 = *reinterpret_cast<const u64_unaligned *>(src + o0), q1 = *reinterpret_cast<const u64_unaligned *>(src + o1);
 #pragma unroll

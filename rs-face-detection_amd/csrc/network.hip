@@ -726,13 +726,19 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
     const bool fork_ok = multi_stream && !profiling && first_op <= 0 && last_op == nops - 1 && side[part][0] && side[part][1];
     bool forked[2] = {false, false};
     // timing-only experiment (results are garbage): RFD_SKIP_OPS="42,45" leaves those ops out of the pass -- the step time without
-    // them bounds what ANY faster kernel for them could buy end to end in the overlapped two-chain pass (tools/ab_bench.sh)
+    // them bounds what ANY faster kernel for them could buy end to end in the overlapped two-chain pass (tools/ab_bench.sh).
+    // Compiled only into diagnostic builds (tools/build_variant.sh ... -DRFD_DIAG): a shipped library never drops an op, whatever
+    // the environment says (the reference returns Err on every failure and never silently wrong detections).
+#ifdef RFD_DIAG
     static const std::vector<int> skip_ops = [] {
         std::vector<int> v;
         if (const char *e = getenv("RFD_SKIP_OPS"))
             for (const char *q = e; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         return v;
     }();
+#else
+    static const std::vector<int> skip_ops;
+#endif
     for (int i = std::max(first_op, 0); i <= last_op; ++i) {
         const Op &o = g.ops[i];
         const Layer &L = g.layers[o.layer];

@@ -119,3 +119,28 @@ def init_comm(det, group=None):
     dist.broadcast_object_list(box, src=0, group=group)
     det.comm_init(box[0], rank, world)
     return rank, world
+
+
+def run_for_at_least(step, sync, seconds, chunk, world=1, device="cpu", clock=None):
+    """Run `step()` in chunks of `chunk` calls, `sync()` behind every chunk, until `seconds` of wall time have passed on ANY
+    rank; returns (elapsed seconds on this rank, steps run).  The decision to stop is collective (an all-reduce MAX of each
+    rank's own verdict), so every rank runs the SAME number of steps: a step of a multi-rank job holds a collective (the RCCL
+    all-gather of the detection slabs), and a rank that left the loop on its own clock while another enqueued one more chunk
+    would hang both.  bench.py's sustained-rate window; world-size-2 test over gloo in tests/test_parallel_cpu.py."""
+    import time
+    import torch
+    import torch.distributed as dist
+    clock = clock or time.perf_counter
+    t0 = clock()
+    steps = 0
+    while True:
+        for _ in range(chunk):
+            step()
+        steps += chunk
+        sync()
+        t1 = clock()
+        stop = torch.tensor([1.0 if t1 - t0 >= seconds else 0.0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+        if float(stop.item()) > 0:
+            return t1 - t0, steps

@@ -158,3 +158,70 @@ def test_rccl_gather_behind_the_c_abi_world_size_1(rfd, det32):
     det.comm_destroy()
     assert det.comm_info() == (0, 0)
     det.set_thresholds(0.7, 0.45)
+
+
+def test_config4_256_frames_of_1080p_as_eight_rank_slices(rfd, oracle, det32):
+    """BASELINE.json configs[3] at its stated size on the one GPU there is: 256 synthetic 1920 x 1080 frames as eight 32-frame
+    rank slices, one after the other through the production path of a rank -- frames resident in HBM, rfd_detect_batch_device
+    with the calls overlapped across slices (async = 2), then the library's RCCL all-gather (rfd_gather_detections; world
+    size 1, so a gather is a stream-ordered copy) INTO THAT RANK'S POSITION of the rank-major 256-frame slab an 8-GPU job
+    assembles.  Every frame is then compared with the oracle (face_detection.rs:131-198 geometry + resize, :319-493 decode /
+    NMS / rescale by det_scale = 1/3): preprocess byte-exact, identical kept sequences (bit-equal scores in order), coordinates
+    within 1e-4 of the NETWORK-scale value (= 3e-4 after the true f32 division by 1/3; bit-identical in practice).
+    What this cannot show is eight real ranks exchanging over xGMI: N > 1 has never run on hardware here."""
+    from rfd_hip import parallel
+    det = det32
+    dev = torch.device("cuda", 0)
+    WORLD, NL = 8, B
+    base = [helpers.make_image(9900 + i, 1080, 1920, n_blobs=10) for i in range(8)]
+
+    def frame(i):   # 256 distinct frames from 8 rendered ones: rolled by a per-frame offset, one channel inverted per group
+        f = np.roll(base[i % 8], shift=(37 * (i // 8), 101 * (i // 8)), axis=(0, 1))
+        if (i // 64) & 1:
+            f = f.copy(); f[..., i % 3] = 255 - f[..., i % 3]
+        return np.ascontiguousarray(f)
+
+    _, tn, _ = det.preprocess([frame(i) for i in range(4)])
+    h4 = det.forward(tn)
+    thr = float(np.quantile(np.concatenate([h4[3 * l][:, 2:4].reshape(-1) for l in range(3)]), 0.994))
+    det.set_thresholds(thr, 0.45)
+    stream = torch.cuda.current_stream()
+    det.set_stream(stream.cuda_stream)
+    det.comm_init(rfd.RetinaFaceDetection.comm_unique_id(), 0, 1)
+    gs = parallel.GatheredSlabs(WORLD, NL, MAX_DET, dev)          # the 256-frame rank-major slab
+    gb, gl, gc, gt = gs.pointers()
+    local = [parallel.DetectionSlab(NL, MAX_DET, device=dev) for _ in range(2)]   # a rank's own slab, double-buffered
+    want, keep_alive = [], []
+    try:
+        for r in range(WORLD):
+            frames = [frame(r * NL + i) for i in range(NL)]
+            rows, _ = _oracle_rows(oracle, det, frames, thr)      # also asserts the byte-exact preprocess of all 32 frames
+            want += rows
+            bufs = [torch.from_numpy(f).to(dev) for f in frames]
+            keep_alive.append(bufs)                               # the frames of a call in flight must stay allocated
+            sl = local[r & 1]
+            det.detect_device([t.data_ptr() for t in bufs], [(1080, 1920)] * NL, *sl.pointers(), async_=2)
+            # rank r's position in the four rank-major arrays
+            dst = (gb + 4 * r * NL * MAX_DET * 5, gl + 4 * r * NL * MAX_DET * 10, gc + 4 * r * NL, gt + 4 * r * NL)
+            det.gather_detections(sl.pointers(), NL, dst)         # stream-ordered behind this slice's NMS
+            if len(keep_alive) > 2:
+                det.sync()
+                keep_alive.pop(0)
+        det.sync()
+        torch.cuda.synchronize()
+        got, tot = gs.unpack()
+    finally:
+        det.comm_destroy()
+        det.set_stream(None)
+        det.set_thresholds(0.7, 0.45)
+    assert len(got) == len(want) == 256
+    nkept = 0
+    for i, ((gd, gk), (od, ok)) in enumerate(zip(got, want)):
+        assert len(gd) == len(od) == tot[i], (i, len(gd), len(od), int(tot[i]))
+        assert np.array_equal(gd[:, 4], od[:, 4]), i                                  # same anchors, same order
+        np.testing.assert_allclose(gd[:, :4], od[:, :4], rtol=0, atol=3e-4, err_msg=str(i))
+        np.testing.assert_allclose(gk, ok, rtol=0, atol=3e-4, err_msg=str(i))
+        nkept += len(od)
+    assert nkept > 256 * 20
+    exact = np.mean([np.array_equal(gd, od) and np.array_equal(gk, ok) for (gd, gk), (od, ok) in zip(got, want)])
+    assert exact > 0.99   # in practice every frame is bit-identical

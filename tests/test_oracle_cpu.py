@@ -285,3 +285,22 @@ def test_resize_and_warp_against_independent_float_bilinear(oracle):
     assert np.percentile(d2, 99.5) <= 0.75 and d2.mean() < 0.2
     inside = (sx > 1) & (sx < W - 2) & (sy > 1) & (sy < H - 2)
     assert inside.sum() > 1000 and (~inside).sum() > 100
+
+
+def test_device_expf_restatement_equals_the_host_libm(oracle):
+    """The decode kernel computes f32::exp (face_detection.rs:534-535) by restating glibc's expf (kernels_post.hip: exp_cr).  The
+    same operation sequence lives in the oracle library as rfd_oracle_expf_restated; here it is pinned against the host libm's
+    expf -- what the oracle (and Rust's f32::exp) calls -- bit for bit: ~4.9 M inputs (every 512th f32 of +-[1e-6, 89], a dense sweep
+    of the box-delta range +-[0, 6], specials).  Scanned offline over 2.2e8 inputs without a difference on a glibc 2.35 / FMA host;
+    on a host whose glibc selects the non-FMA build of expf about 3 inputs in 10^9 differ by one ulp, hence the bar of 1."""
+    lo, hi = np.float32(1e-6).view(np.uint32), np.float32(89.0).view(np.uint32)
+    pos = np.arange(int(lo), int(hi), 512, dtype=np.uint32).view(np.float32)
+    dense = np.linspace(-6, 6, 4_000_001, dtype=np.float64).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 88.7, 88.8, 89.0, -103.9, -104.0, -87.5, 1e-40, -1e-40, float.fromhex('0x1.62e42ep6'), -float.fromhex('0x1.9fe368p6')], np.float32)
+    x = np.concatenate([pos, -pos, dense, special])
+    a, b = oracle.expf(x, restated=True), oracle.expf(x)
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert x.size > 4_500_000 and int((~same).sum()) <= 1, "restated expf differs from the host libm at %s" % x[~same][:8]
+    # and it is NOT the correctly rounded value everywhere: the reason the restatement exists
+    cr = np.exp(dense.astype(np.float64)).astype(np.float32)
+    assert 1e-6 < np.mean(cr != oracle.expf(dense)) < 1e-2

@@ -111,6 +111,45 @@ def test_gather_world_size_2_matches_single_process(total):
         assert res[i][0] == []
 
 
+def _sustain_worker(rank, world, port, q):
+    import time
+    import torch
+    import torch.distributed as dist
+    from rfd_hip import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.zeros(1)
+
+    def step():                       # a step with a collective in it, and ranks of very different speed
+        time.sleep(0.02 if rank == 0 else 0.001)
+        dist.all_reduce(x)
+    # rank 1 starts its window late: with per-rank stop decisions rank 0 would leave one chunk earlier and both would hang
+    if rank == 1:
+        time.sleep(0.15)
+    el, steps = parallel.run_for_at_least(step, lambda: None, 0.5, 5, world, "cpu")
+    dist.barrier()
+    q.put((rank, steps, el))
+    dist.destroy_process_group()
+
+
+def test_sustained_window_stops_collectively_world_size_2():
+    """bench.py's sustained-rate loop (round-3 advisor finding): all ranks must run the same number of steps although their
+    clocks start apart and their steps differ in speed."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sustain_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][1] >= 5
+    assert max(g[2] for g in got) >= 0.5
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus N` with WORLD_SIZE unset must start N rank processes itself (the driver's multi-GPU
     command), relay rank 0's single JSON line and return the children's status.  Rehearsed on CPU: RFD_BENCH_DRYRUN makes

@@ -135,6 +135,78 @@ def test_t2_f32_parity_mode_vs_f32_network(rfd, oracle, t2_setup):
     assert all(all(m < 2e-6 for m in margins) for _, _, margins in flips) and len(flips) <= 1, flips
 
 
+def _ulp_distance(a, b):
+    """distance in f32 units in the last place between two f32 arrays (sign-magnitude ordered integers)"""
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+def test_t2_f32_parity_mode_meets_1e_4_against_the_f64_accumulating_walk(rfd, oracle, t2_setup):
+    """north_star's bar END TO END (round 4): identical kept-index sets and every coordinate within 1e-4, on all 32 frames.
+
+    Both sides evaluate the same folded graph with f32 tensors and f64-ACCUMULATED convolutions rounded once per output: the
+    device in its f32 parity mode (csrc/kernels_f32.hip) and torch-CPU through tests/torch_ref.py (acc64=True: F.conv2d in float64,
+    `.float()` per layer, the elementwise steps in the device's order).  A product of two f32 values is exact in f64, so each side
+    computes the correctly rounded value of the same exact sum; they differ only where ~K * 2^-53 of summation-order noise
+    straddles an f32 rounding boundary (about one output in 10^5), and such a one-ulp seed stays ~1e-7 relative downstream.
+    The heads are compared in ulps; the detections through the oracle's decode / NMS (face_detection.rs:319-493) of the torch
+    heads against the device's rows.  Any residual above 1e-4 would be listed with its head-tensor ulp distance."""
+    import torch
+    import torch_ref
+    from rfd_hip import convert
+    P, frames, tensor, f32_heads, delta = t2_setup
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    det = rfd.RetinaFaceDetection(max_batch_size=N, max_det=2048, confidence_threshold=THR, iou_threshold=IOU_THR,
+                                  precision=rfd.PRECISION_F32)
+    convert.import_unfolded(det, g, P)
+    dev_heads = det.forward(tensor)
+    dev_rows = det.decode_nms(dev_heads, np.ones(N, np.float32), want_gidx=True)
+    ref = torch_ref.TorchRef(g, det, round_bf16=False, acc64=True)   # the folded f32 parameters the device reports
+    ref_heads = []
+    for i in range(0, N, 4):
+        x4 = torch.cat([torch.from_numpy(tensor[i:i + 4]), torch.zeros(4, 1, 640, 640)], 1)
+        ref_heads.append(ref.heads(ref.forward(x4)))
+    ref_heads = [np.concatenate([c[k] for c in ref_heads], 0) for k in range(9)]
+    names = ["%s%d" % (t, st) for st in (32, 16, 8) for t in ("cls", "bbox", "lmk")]
+    ulp = {n: _ulp_distance(np.ascontiguousarray(a), np.ascontiguousarray(b)) for n, a, b in zip(names, dev_heads, ref_heads)}
+    stats = {n: {"identical_frac": float(np.mean(u == 0)), "max_ulp": int(u.max()), "p999_ulp": float(np.percentile(u, 99.9))} for n, u in ulp.items()}
+    print("f32 mode (f64 accumulation) vs torch f64-accumulating walk, heads in ulps:", json.dumps(stats))
+    kept = 0
+    residuals, set_diffs = [], []
+    worst_coord = worst_score = 0.0
+    for b in range(N):
+        odet, olmk, ogidx, _ = oracle.decode_nms([h[b] for h in ref_heads], 640, 640, np.float32(THR), IOU_THR, 1.0)
+        gdet, glmk, ggidx = dev_rows[b]
+        kept += len(ogidx)
+        if not np.array_equal(ggidx, ogidx):
+            sf = _fg_scores(ref_heads, b)
+            only = sorted(set(ogidx.tolist()) ^ set(ggidx.tolist()))
+            set_diffs.append((b, only, [float(abs(sf[a] - THR)) for a in only]))
+            continue
+        dc = np.concatenate([np.abs(gdet[:, :4] - odet[:, :4]).reshape(len(odet), -1), np.abs(glmk - olmk).reshape(len(odet), -1)], 1)
+        worst_coord = max(worst_coord, float(dc.max(initial=0)))
+        worst_score = max(worst_score, float(np.abs(gdet[:, 4] - odet[:, 4]).max(initial=0)))
+        for i in np.argwhere(dc.max(1) > 1e-4).ravel():
+            residuals.append({"frame": b, "anchor": int(ogidx[i]), "coord_diff_px": float(dc[i].max())})
+    m = {"frames": N, "kept": kept, "heads_ulp": stats, "frames_with_differing_kept_set": set_diffs, "coords_over_1e-4": residuals,
+         "worst_coord_abs_diff_px": worst_coord, "worst_score_abs_diff": worst_score}
+    print("f32 mode (f64 accumulation): kept %d boxes over %d frames; differing kept sets %s; worst coordinate %.3g px, score %.3g; residuals %s"
+          % (kept, N, set_diffs, worst_coord, worst_score, residuals))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(m, open(os.path.join(ROOT, "gpurun_out", "t2_f32_mode_f64acc_metrics.json"), "w"), indent=1)
+    except OSError:
+        pass
+    det.close()
+    assert kept > 300
+    assert not set_diffs, set_diffs                       # identical kept-index sequences on every frame
+    assert not residuals and worst_coord <= 1e-4          # north_star's coordinate bar, end to end
+    assert worst_score <= 2e-6                            # the softmax's exp differs between the device's libm and torch's
+    assert all(v["identical_frac"] > 0.9 for k, v in stats.items() if not k.startswith("cls")), stats
+
+
 def test_t2_bf16_network_vs_f32_network(rfd, oracle, t2_setup):
     from rfd_hip import convert
     P, frames, tensor, f32_heads, delta = t2_setup

@@ -11,17 +11,45 @@ import torch.nn.functional as F
 
 
 _ROUND = [True]  # TorchRef(round_bf16=False) evaluates the same op list WITHOUT the bf16 roundings: the f32 parity mode's reference
+_ACC64 = [False]  # TorchRef(acc64=True): convolutions summed in f64 and rounded to f32 ONCE per output, elementwise steps in the
+                  # device's order (csrc/kernels_f32.hip since round 4) -- two such evaluations agree to the ulp
 
 
 def bf16r(t):
     return t.to(torch.bfloat16).to(torch.float32) if _ROUND[0] else t
 
 
+def conv(x, w, b, stride=1, padding=0, groups=1, x2=None, w2=None, b2=None, stride2=1):
+    """conv2d + bias (+ a second 1x1 conv fused as K segment).  acc64: both sums in ONE f64 accumulator, rounded to f32 once,
+    then + (b + b2) in f32 -- the device kernel's order (conv_f32_kernel: `(float)acc + bias`, bias = bias + bias2)."""
+    if not _ACC64[0]:
+        v = F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
+        if x2 is not None:
+            v = v + F.conv2d(x2, w2, b2, stride=stride2)
+        return v
+    s = F.conv2d(x.double(), w.double(), None, stride=stride, padding=padding, groups=groups)
+    bias = b
+    if x2 is not None:
+        s = s + F.conv2d(x2.double(), w2.double(), None, stride=stride2)
+        bias = b + b2
+    return s.float() + bias.view(1, -1, 1, 1)
+
+
+def affine_in(x, s, t):
+    """the producer unit's BN + ReLU on a conv operand.  The device applies it as ONE fused multiply-add (fmaf) in the f32 parity
+    mode; x * s is exact in f64, so the f64 expression rounded once reproduces fmaf (but for double-rounding cases ~2^-29)."""
+    if _ACC64[0]:
+        return F.relu((x.double() * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1)).float())
+    return F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1))
+
+
 class TorchRef:
-    def __init__(self, graph, det, round_bf16=True):
+    def __init__(self, graph, det, round_bf16=True, acc64=False):
         """graph: rfd_hip.Graph; det: rfd_hip.RetinaFaceDetection with initialised weights."""
         self.g = graph
         self.round_bf16 = round_bf16
+        self.acc64 = acc64
+        assert not (acc64 and round_bf16), "acc64 is the reference of the f32 parity mode"
         self.w, self.b, self.aff = [], [], []
         for i, L in enumerate(graph.layers):
             w, b = det.get_layer(i, L)
@@ -42,7 +70,7 @@ class TorchRef:
         if o.kind == 2 and x.shape[1] != L.cin:  # the input is a channel slice of a wider tensor
             x = x[:, o.x_coff:o.x_coff + L.cin]
         if o.kind == 0:  # conv0 7x7/2 on R,G,B (+ zero 4th channel) + bias + relu
-            v = F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
+            v = conv(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)
             tensors[o.out] = bf16r(F.relu(v))
             return
         if o.kind == 5:  # first 3x3/2 conv on R,G,B + bias + relu (MobileNet)
@@ -53,7 +81,7 @@ class TorchRef:
                                                    groups=L.cout)))
             return
         if o.kind == 3:  # fused stem: conv0 + bias + relu (bf16) -> maxpool 3x3/2 pad 1 -> affine + relu
-            v = bf16r(F.relu(F.conv2d(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)))
+            v = bf16r(F.relu(conv(x[:, :3], self.w[o.layer], self.b[o.layer], stride=2, padding=3)))
             s, t = self.aff[o.layer]
             tensors[o.out] = bf16r(F.relu(F.max_pool2d(v, 3, 2, 1) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
             return
@@ -64,15 +92,16 @@ class TorchRef:
             return
         if o.in_affine >= 0:  # BN+ReLU of the producer unit, applied to this conv's input (rounded to bf16)
             s, t = self.aff[o.in_affine]
-            x = bf16r(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+            x = bf16r(affine_in(x, s, t))
         wgt, bias = self.w[o.layer], self.b[o.layer]
         if o.layer_n2 >= 0:  # sibling conv on the same input fused along N: its output channels follow
             wgt = torch.cat([wgt, self.w[o.layer_n2]], 0)
             bias = torch.cat([bias, self.b[o.layer_n2]], 0)
-        v = F.conv2d(x, wgt, bias, stride=L.stride, padding=L.pad)
         if o.layer2 >= 0:  # the 1x1 shortcut conv fused as a second K segment of the same GEMM
             L2 = g.layers[o.layer2]
-            v = v + F.conv2d(tensors[o.in2], self.w[o.layer2], self.b[o.layer2], stride=L2.stride)
+            v = conv(x, wgt, bias, stride=L.stride, padding=L.pad, x2=tensors[o.in2], w2=self.w[o.layer2], b2=self.b[o.layer2], stride2=L2.stride)
+        else:
+            v = conv(x, wgt, bias, stride=L.stride, padding=L.pad)
         r = None
         if o.res >= 0:
             r = tensors[o.res]
@@ -102,10 +131,10 @@ class TorchRef:
         if o.kind == 6:  # back to back: the next unit's conv1 on relu(affine(bf16 raw)), bias + relu
             s, tt = self.aff[o.layer]
             if o.out >= 0:
-                a = bf16r(F.relu(tensors[o.out] * s.view(1, -1, 1, 1) + tt.view(1, -1, 1, 1)))
+                a = bf16r(affine_in(tensors[o.out], s, tt))
             else:            # the last unit of a stage: only the activated output exists; conv1 reads it as stored
                 a = tensors[o.out2]
-            tensors[o.out_b] = bf16r(F.relu(F.conv2d(a, self.w[o.layer_b], self.b[o.layer_b])))
+            tensors[o.out_b] = bf16r(F.relu(conv(a, self.w[o.layer_b], self.b[o.layer_b])))
         if o.outf >= 0:
             if o.head_softmax:  # channels 0,1 = bg(a), 2,3 = fg(a): softmax over the pairs (a, A+a)
                 pr = torch.softmax(torch.stack([v[:, 0:2], v[:, 2:4]], 0), 0)
@@ -117,12 +146,14 @@ class TorchRef:
         tensors = {next(i for i, t in enumerate(self.g.tensors) if t.is_input): x_nchw4}
         last = len(self.g.ops) - 1 if upto is None else upto
         _ROUND[0] = self.round_bf16
+        _ACC64[0] = self.acc64
         try:
             with torch.no_grad():
                 for i in range(last + 1):
                     self.run_op(i, tensors)
         finally:
             _ROUND[0] = True
+            _ACC64[0] = False
         return tensors
 
     def heads(self, tensors):
