@@ -344,6 +344,10 @@ RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
 /* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal, 17 = the
  * wave-specialised ring form wherever the layer shape allows (the full list: launch_conv in csrc/kernels_conv.hip) */
 RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
+/* which kernel(s) op `op` of the network would be run by at `n` images per chain (co_running != 0: as one of the two chains of a
+ * split pass) -- the names rocprofv3 reports without the rfd:: prefix, " + "-separated when an op takes two launches.  Nothing is
+ * launched.  tools/traffic_model.py and tools/roof_gap.py attribute bytes and time to kernels through this call. */
+RFD_API int rfd_debug_op_kernels(rfd_ctx *ctx, int n, int op, int co_running, char *names, int cap);
 /* execution structure of the network pass: side streams for independent chains on/off; batch split into
  * clamp(n / split_min_part, 1, split_max_parts) contiguous parts that run as independent chains on their own streams
  * (split_max_parts <= 1 = never; at most 4); hipGraph replay of unsplit passes on/off.  Every structure gives

@@ -14,6 +14,25 @@
 namespace rfd {
 
 static thread_local char g_err[512] = "";
+LaunchNote &launch_note()
+{
+    static thread_local LaunchNote n;
+    return n;
+}
+bool note_launch(const char *fmt, ...)
+{
+    LaunchNote &n = launch_note();
+    if (!n.dry) return false;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (!n.names.empty()) n.names += " + ";
+    n.names += buf;
+    return true;
+}
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -886,6 +905,29 @@ int rfd_debug_run_ops(rfd_ctx *c, int n, int first_op, int last_op)
     RFD_HIP(hipStreamSynchronize(c->stream));
     if (c->net.profiling) RFD_TRY(c->net.collect_profile());
     return check_nms_flag(c);
+}
+
+int rfd_debug_op_kernels(rfd_ctx *c, int n, int op, int co_running, char *names, int cap)
+{
+    RFD_CHECK_ARG(c && names && cap > 0, "null argument");
+    RFD_HIP(hipSetDevice(c->cfg.device_id));
+    RFD_TRY(c->ensure_network());
+    RFD_CHECK_ARG(n >= 1 && n <= c->cfg.max_batch_size && op >= 0 && op < (int)c->net.g.ops.size(), "batch or op out of range");
+    if (c->net.precision != 0) { set_error("kernel-choice introspection covers the bf16 path"); return RFD_ERR_STATE; }
+    LaunchNote &note = launch_note();
+    note.names.clear();
+    note.dry = true;                       // every launch path records its kernel and returns without launching
+    const int saved = c->net.co_running;
+    const bool prof = c->net.profiling;
+    c->net.co_running = co_running != 0;   // as for a chain of a split pass (batches >= 16 run as two chains of n / 2 images)
+    c->net.profiling = false;
+    const int st = c->net.run(n, c->stream, op, op);
+    c->net.co_running = saved;
+    c->net.profiling = prof;
+    note.dry = false;
+    RFD_TRY(st);
+    snprintf(names, (size_t)cap, "%s", note.names.c_str());
+    return RFD_OK;
 }
 
 // ---- weights ----

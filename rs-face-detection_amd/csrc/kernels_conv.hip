@@ -990,6 +990,7 @@ int persistent_kernel_table(int i, const char **name, size_t *lds_bytes)
 }
 template <auto Kern, typename... A> static int launch_persistent(int grid, size_t lds_need, hipStream_t s, A... args)
 {
+    if (launch_note().dry) return RFD_OK; // the caller has recorded the kernel's name (note_launch)
     static const bool exact = [] { const char *e = getenv("RFD_PERSIST_LDS_EXACT"); return e && atoi(e) != 0; }();
     if (lds_need > kPersistentLds) { set_error("persistent kernel: %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
     static DynLdsOnce once;
@@ -1014,6 +1015,7 @@ template <int NK, bool HAS_Y, bool HAS_Y2> static int launch_pw_stream(const Con
     // write-after-read race on the weight ring in this kernel's ISA (bare s_barrier with ds_reads in flight, now
     // `s_waitcnt lgkmcnt(0)` + barrier) that the padding may only have masked; the padding stays as the rule either way.
     const size_t lds_need = (size_t)(NK * 128 + (NK + 1) * 128) * 64 * sizeof(bf16_t) + (size_t)3 * p.Cout * sizeof(float);
+    note_launch("pw_stream_kernel<%d, %s, %s>", NK, HAS_Y ? "true" : "false", HAS_Y2 ? "true" : "false");
     return launch_persistent<pw_stream_kernel<NK, HAS_Y, HAS_Y2>>(grid, lds_need, s, p);
 }
 template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hipStream_t s)
@@ -1024,6 +1026,7 @@ template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hi
     const int per = ceil_div(tiles_m, ncu);
     const int grid = ceil_div(tiles_m, per);
     const size_t lds_need = (size_t)(NK + 2 + NK + 3) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128) * sizeof(float);
+    note_launch("pw_b2b_kernel<%d, %s>", NK, ACT_OUT ? "true" : "false");
     return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
 }
 template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
@@ -1036,6 +1039,7 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int la
     const size_t slots = NCR ? (size_t)NCR * (NK + NK2 + 2 * N1B) : (size_t)(NK + NK2 + 2 * N1B + 1);
     const size_t lds_need = slots * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
     if (NCR && p.Cout != NCR * 128) { set_error("pw_pair: resident form instantiated for %d output channels", NCR * 128); return RFD_ERR_INVALID_ARG; }
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, %d>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
     return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2, NCR>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
@@ -1347,6 +1351,7 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
     // needs 154 KiB; launch_persistent asks for the whole CU's LDS so that no other kernel's workgroup can ever share the CU
     constexpr size_t lds_need = (size_t)(9 * 64 * 64 + 2 * kC64HP * 512) * sizeof(bf16_t);
     static_assert(lds_need <= kPersistentLds, "LDS");
+    note_launch("conv3x3_c64_kernel");
     return launch_persistent<conv3x3_c64_kernel>(grid, lds_need, s, p, tiles_x, tiles_y);
 }
 
@@ -1607,6 +1612,7 @@ template <int TC, int TR, int TN> static int launch_conv3x3_halo(const ConvParam
     const int grid = ceil_div(n_items, per);
     constexpr int HP = ((TR + 2) * (TC + 2) + 7) / 8, U = TN == 4 ? 2 : 1;
     constexpr size_t lds_need = (size_t)(2 * HP * 512 + 2 * U * 32 * TN * 64) * 2 + 2048; // two halo buffers, two weight slots, tables
+    note_launch("conv3x3_halo_kernel<%d, %d, %d>", TC, TR, TN);
     return launch_persistent<conv3x3_halo_kernel<TC, TR, TN>>(grid, lds_need, s, p, tiles_x, tiles_y, n_items);
 }
 
@@ -1619,6 +1625,7 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
     auto kern = conv3x3_kx_kernel<BN, WAVES_M, WAVES_N>;
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)lds));
+    if (note_launch("conv3x3_kx_kernel<%d, %d, %d>", BN, WAVES_M, WAVES_N)) return RFD_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -1888,6 +1895,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
 template <bool AFF, bool WIDE> static int launch_pw_gemm_t(const ConvParams &p, hipStream_t s, int tiles_m, int n_items, int grid)
 {
     // 3 activation + 2 weight slots + tables: the whole CU
+    note_launch("pw_gemm_kernel<%s, %s>", AFF ? "true" : "false", WIDE ? "true" : "false");
     return launch_persistent<pw_gemm_kernel<AFF, WIDE>>(grid, kPersistentLds, s, p, tiles_m, n_items);
 }
 
@@ -2120,6 +2128,7 @@ static int launch_pw_wide(const ConvParams &p, hipStream_t s)
     const int per = ceil_div(n_items, ncu);
     const int grid = ceil_div(n_items, per);
     // 4 x 32 KiB + tables: the whole CU
+    note_launch("pw_wide_kernel");
     return launch_persistent<pw_wide_kernel>(grid, kPersistentLds, s, p, n_items);
 }
 
@@ -2633,15 +2642,18 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
         const int per = ceil_div(ntiles, persistent_cus(1, true));
         const int grid = ceil_div(ntiles, per);
+        note_launch("conv_b2b_s1_persistent_kernel");
         return launch_persistent<conv_b2b_s1_persistent_kernel>(grid, kPersistentLds, s, p, ntiles);
     }
     // K1 = 128 (fused shortcut, no residual): persistent 64-pixel tiles, both filter banks resident
     if (p.Cin2 == 64 && !p.res && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (M >= 64 * 1024 || p.force_tile == 6)) {
         const int nt = ceil_div(M, 64), per = ceil_div(nt, persistent_cus(1, true));
+        note_launch("conv_b2b_s1_persistent_k128_kernel");
         return launch_persistent<conv_b2b_s1_persistent_k128_kernel>(ceil_div(nt, per), kPersistentLds, s, p, nt);
     }
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(conv_b2b_s1_kernel), (int)lds));
+    if (note_launch("conv_b2b_s1_kernel")) return RFD_OK;
     hipLaunchKernelGGL(conv_b2b_s1_kernel, dim3(ceil_div(M, 128)), dim3(512), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -2660,6 +2672,7 @@ static int launch_conv_cfg_order(const ConvParams &p, hipStream_t s)
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, NSX, CHUNK_MAJOR>;
     static DynLdsOnce once;
     RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)(full + 16384)));
+    if (note_launch("conv_igemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WAVES_M, WAVES_N, NSX, CHUNK_MAJOR ? "true" : "false")) return RFD_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -2929,6 +2942,7 @@ int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y
     }
     const long long ntile = ((long long)B * (H / 2) * (W / 2) + 15) / 16;
     const int grid = (int)std::min<long long>((ntile + 3) / 4, 256 * 8);
+    if (note_launch("conv0_kernel")) return RFD_OK;
     hipLaunchKernelGGL(conv0_kernel, dim3(grid), dim3(256), 0, s, x4, w, bias, y, B, H, W);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
@@ -3087,6 +3101,7 @@ int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const floa
     }
     const int Hp = H / 4, Wp = W / 4;
     const int tiles_h = ceil_div(Hp, kStemPH), tiles_w = ceil_div(Wp, kStemPW);
+    if (note_launch("stem_kernel")) return RFD_OK;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(B * tiles_h * tiles_w)), dim3(256), 0, s, x4, w, bias, scale, shift, y,
                        H, W, tiles_w, tiles_h);
     RFD_HIP(hipGetLastError());
@@ -3145,6 +3160,7 @@ int launch_maxpool3x3s2(const bf16_t *x, bf16_t *y, const float *scale, const fl
 {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)B * Ho * Wo * (C / 8);
+    if (note_launch("maxpool_kernel")) return RFD_OK;
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, scale,
                        shift, B, H, W, C, Ho, Wo);
     RFD_HIP(hipGetLastError());
@@ -3204,6 +3220,7 @@ int launch_first3x3(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t
 {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)B * Ho * Wo;
+    if (note_launch("first3x3_kernel")) return RFD_OK;
     hipLaunchKernelGGL(first3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x4,
                        reinterpret_cast<const uint32_t *>(w), bias, y, B, H, W, Ho, Wo, Cd);
     RFD_HIP(hipGetLastError());
@@ -3257,6 +3274,7 @@ int launch_dwconv3x3(const bf16_t *x, const bf16_t *w, const float *bias, bf16_t
 {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long long total = (long long)B * Ho * Wo * (C / 8);
+    if (note_launch("dwconv3x3_kernel")) return RFD_OK;
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, y, B, H, W,
                        C, Ho, Wo, stride);
     RFD_HIP(hipGetLastError());

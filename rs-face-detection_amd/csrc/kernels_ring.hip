@@ -444,6 +444,7 @@ int launch_conv_ring(const ConvParams &p, hipStream_t s)
     do {                                                                                     \
         auto kern = conv_ring_kernel<KX, CM>;                                                \
         static DynLdsOnce once;                                                              \
+        if (note_launch("conv_ring_kernel<%s, %s>", KX ? "true" : "false", CM ? "true" : "false")) return RFD_OK; \
         RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)lds));                \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);                          \
     } while (0)

@@ -75,6 +75,17 @@ constexpr int kDetRow = 16;                       // floats per decoded row: box
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- kernel-choice introspection (rfd_debug_op_kernels): with `dry` set on the calling thread, every launch path records the
+//      kernel it WOULD launch (the name rocprofv3 reports, without the rfd:: prefix) and returns without launching.  The tools
+//      that attribute time / traffic to kernels (tools/traffic_model.py, tools/roof_gap.py) ask the library instead of
+//      mirroring launch_conv()'s rules (round-3 review: the mirror had gone stale).
+struct LaunchNote {
+    bool dry = false;
+    std::string names; // " + "-separated
+};
+LaunchNote &launch_note();
+bool note_launch(const char *fmt, ...); // true: dry run, the caller returns RFD_OK without launching
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: one flag per (kernel, device),
 // read and set atomically (the attribute call itself is idempotent, so two threads racing through it is harmless).
 // Usage: `static DynLdsOnce once; RFD_TRY(once.ensure(kernel_ptr, bytes));` next to the launch.

@@ -99,7 +99,7 @@ API_SYMBOLS = [
     "rfd_set_layer_weights", "rfd_get_layer_affine", "rfd_set_layer_affine", "rfd_detect_batch",
     "rfd_detect_batch_device", "rfd_sync", "rfd_set_stream", "rfd_preprocess", "rfd_forward", "rfd_decode_nms",
     "rfd_nms_sorted", "_nms", "rfd_get_stats", "rfd_get_config", "rfd_set_thresholds", "rfd_set_profiling",
-    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_debug_set_concurrency", "rfd_debug_persistent_kernel", "rfd_debug_poke_nms_flag", "rfd_selection_config_default",
+    "rfd_get_conv_profile", "rfd_get_op_profile", "rfd_debug_tensor_io", "rfd_debug_run_ops", "rfd_debug_set_conv_tile", "rfd_debug_op_kernels", "rfd_debug_set_concurrency", "rfd_debug_persistent_kernel", "rfd_debug_poke_nms_flag", "rfd_selection_config_default",
     "rfd_select_faces", "rfd_detect_select_batch", "rfd_save_weights", "rfd_load_weights",
     "rfd_alignment_config_default", "rfd_align_faces", "rfd_detect_select_align_batch",
     "rfd_host_alloc", "rfd_host_free", "rfd_submit_batch", "rfd_collect_batch",
@@ -163,6 +163,7 @@ def load_library(path=None):
     L.rfd_debug_run_ops.argtypes = [vp, ci, ci, ci]
     L.rfd_debug_set_conv_tile.argtypes = [vp, ci]
     L.rfd_debug_set_concurrency.argtypes = [vp, ci, ci, ci, ci]
+    L.rfd_debug_op_kernels.argtypes = [vp, ci, ci, ci, C.c_char_p, ci]
     L.rfd_debug_poke_nms_flag.argtypes = [vp, ci]
     L.rfd_debug_persistent_kernel.argtypes = [ci, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.rfd_save_weights.argtypes = [vp, C.c_char_p]
@@ -582,6 +583,12 @@ class RetinaFaceDetection:
 
     def debug_set_conv_tile(self, tile):
         _check(self._L.rfd_debug_set_conv_tile(self._ctx, tile))
+
+    def debug_op_kernels(self, n, op, co_running=True):
+        """kernel(s) the library would run op `op` with at n images per chain (list of names, no rfd:: prefix); nothing is launched"""
+        buf = C.create_string_buffer(512)
+        _check(self._L.rfd_debug_op_kernels(self._ctx, n, op, 1 if co_running else 0, buf, 512))
+        return buf.value.decode().split(" + ")
 
     def debug_set_concurrency(self, multi_stream=True, split_min_part=8, split_max_parts=2, use_graph=True):
         _check(self._L.rfd_debug_set_concurrency(self._ctx, int(multi_stream), int(split_min_part), int(split_max_parts),

@@ -44,12 +44,15 @@ def affine_in(x, s, t):
 
 
 class TorchRef:
-    def __init__(self, graph, det, round_bf16=True, acc64=False):
-        """graph: rfd_hip.Graph; det: rfd_hip.RetinaFaceDetection with initialised weights."""
+    def __init__(self, graph, det, round_bf16=True, acc64=False, round_ops=None):
+        """graph: rfd_hip.Graph; det: rfd_hip.RetinaFaceDetection with initialised weights.
+        round_ops: set of op indices whose stored tensors are rounded to bf16 (all others stay f32) -- the probe of the bf16 error
+        budget (tools/error_budget.py); None: every op rounds, or none, as round_bf16 says."""
         self.g = graph
         self.round_bf16 = round_bf16
         self.acc64 = acc64
-        assert not (acc64 and round_bf16), "acc64 is the reference of the f32 parity mode"
+        self.round_ops = round_ops
+        assert not (acc64 and (round_bf16 or round_ops)), "acc64 is the reference of the f32 parity mode"
         self.w, self.b, self.aff = [], [], []
         for i, L in enumerate(graph.layers):
             w, b = det.get_layer(i, L)
@@ -150,6 +153,8 @@ class TorchRef:
         try:
             with torch.no_grad():
                 for i in range(last + 1):
+                    if self.round_ops is not None:
+                        _ROUND[0] = i in self.round_ops
                     self.run_op(i, tensors)
         finally:
             _ROUND[0] = True

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per op (B = 16 section of a tools/op_bench.py table): time next to its two floors -- MFMA at 2.5 PF/s and HBM at 5 TB/s
 (algorithmic bytes: every tensor the op reads or writes once) -- sorted by the time above the larger floor.  Host only.
-usage: python tools/roof_gap.py profiles/r02_final_per_op_b16_b32.txt"""
+The kernel column is the library's own op -> kernel answer (tools/op_kernels.py -> JSON, optional second argument).
+usage: python tools/roof_gap.py profiles/rNN_per_op_b16_b32.txt [profiles/rNN_op_kernels_b16.json]"""
+import json
 import os
 import re
 import sys
@@ -12,6 +14,7 @@ import rfd_hip  # noqa: E402
 
 B = 16
 g = rfd_hip.Graph(rfd_hip.BACKBONE_R50, 640, 640)
+kmap = json.load(open(sys.argv[2]))["ops"] if len(sys.argv) > 2 else {}
 times = {}
 sec = None
 for ln in open(sys.argv[1]):
@@ -44,7 +47,7 @@ for i, us in times.items():
     rows.append((us - floor, i, L.name.decode(), us, t_mfma, t_hbm, "mfma" if t_mfma > t_hbm else "hbm"))
 rows.sort(reverse=True)
 tot = sum(r[3] for r in rows)
-print("%3s %-22s %8s %8s %8s %5s %8s   (B = %d, sum %.0f us)" % ("op", "layer", "us", "mfma us", "hbm us", "bound", "above", B, tot))
+print("%3s %-22s %8s %8s %8s %5s %8s  %s   (B = %d, sum %.0f us)" % ("op", "layer", "us", "mfma us", "hbm us", "bound", "above", "kernel", B, tot))
 for above, i, nm, us, tm, th, bd in rows:
-    print("%3d %-22s %8.1f %8.1f %8.1f %5s %8.1f" % (i, nm, us, tm, th, bd, above))
+    print("%3d %-22s %8.1f %8.1f %8.1f %5s %8.1f  %s" % (i, nm, us, tm, th, bd, above, " + ".join(kmap.get(str(i), {}).get("kernels", []))))
 print("sum of floors %.0f us" % sum(max(r[4], r[5]) for r in rows))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Algorithmic HBM bytes per forward pass (B = 32) per kernel class -- every tensor an op reads / writes counted once
 (weights excluded: 54 MB per pass in total) -- next to the PMC traffic of profiles/*hbm_traffic.json.  The op -> kernel
-mapping mirrors launch_conv() for the split (co-running) mode.  Host only."""
+mapping is the library's own (tools/op_kernels.py -> JSON, second argument).  Host only.
+usage: python tools/traffic_model.py profiles/rNN_hbm_traffic.json profiles/rNN_op_kernels_b16.json"""
 import json
 import os
 import sys
@@ -22,51 +23,23 @@ def tbytes(t, ch=None):
     return (ch if ch else T.channels) * T.height * T.width * (4 if T.is_f32 else 2) * B
 
 
-BC = 16  # images per chain in the timed (split) mode: the size rules of launch_conv() see this batch
+# op -> kernel: the library's own answer (tools/op_kernels.py on the GPU box -> profiles/rNN_op_kernels_b16.json), not a mirror of
+# launch_conv()'s rules
+kmap = json.load(open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "op_kernels_latest.json")))["ops"]
 
 
-def conv_class(o, L, n_out):
-    """The kernel launch_conv() picks for this op at BC images (mirrors its order of tests)."""
-    tin = g.tensors[o.in_]
-    tout = g.tensors[o.out if o.out >= 0 else (o.out2 if o.out2 >= 0 else o.outf)]
-    M = BC * tout.height * tout.width
-    plain_out = o.outf < 0 and o.layer_b < 0
-    if L.kh == 1 and L.stride == 1 and o.res >= 0 and o.layer2 < 0 and o.in_affine < 0 and L.cin in (64, 128, 256) and L.cout >= 4 * L.cin \
-            and L.cout <= 1024 and not o.res_up2 and not o.res_post and plain_out and M >= 128 * 128:
-        return "rfd::pw_stream_kernel"
-    if L.kh == 1 and L.stride == 1 and o.layer2 < 0 and o.out2 < 0 and plain_out and L.cin % 128 == 0 and 256 <= L.cin <= 2048 \
-            and L.cout % 128 == 0 and L.cout <= 1024 and -(-M // 256) * (L.cout // 128) >= (400 if o.res >= 0 else 150):
-        return "rfd::pw_gemm_kernel"
-    kk = L.cin + (g.layers[o.layer2].cin if o.layer2 >= 0 else 0)
-    if L.kh == 1 and L.stride == 1 and o.in_affine < 0 and plain_out and kk >= 384 and L.cout % 256 == 0 and 512 <= L.cout <= 2048 \
-            and not o.res_up2 and not o.res_post and -(-M // 256) * (L.cout // 256) >= 150:
-        return "rfd::pw_wide_kernel"
-    if L.kh == 3 and L.stride == 1 and L.cin == 64 and L.cout == 64 and o.layer_n2 < 0 and M >= 96 * 256:
-        return "rfd::conv3x3_c64_kernel"
-    if L.kh == 3 and L.stride == 1 and L.cin % 128 == 0 and (n_out % 128 == 0 or n_out == 192) and n_out <= 512 and o.res < 0 \
-            and (tin.width % 16 == 0 or tin.width == 40):
-        tiles = BC * (-(-tin.height // 6) if tin.width == 40 else (tin.width // 16) * -(-tin.height // 16))
-        if (n_out == 192 and tiles >= 100) or (n_out != 192 and tiles * (n_out // 128) >= 200):
-            return "rfd::conv3x3_halo_kernel"
-    if L.kh == 3 and L.stride == 1 and n_out % 128 == 0 and o.layer2 < 0:
-        return "rfd::conv3x3_kx_kernel"
-    return "rfd::conv_igemm_kernel"
+def op_class(i):
+    ks = kmap[str(i)]["kernels"]
+    return "rfd::" + ks[0].split("<")[0] if len(ks) == 1 else " + ".join("rfd::" + k.split("<")[0] for k in ks)
 
 
 cls = {}
 for i, o in enumerate(g.ops):
     L = g.layers[o.layer]
     n_out = L.cout + (g.layers[o.layer_n2].cout if o.layer_n2 >= 0 else 0)
-    if o.kind == 3:
-        k = "rfd::stem_kernel"
-    elif o.kind == 6:
-        Lb = g.layers[o.layer_b]
-        # stage 1's own kernels / round 3's pair kernels (stage 3: the register-operand form)
-        k = "rfd::conv_b2b_s1_kernel" if (L.cin == 64 and Lb.cout == 64) else ("rfd::pw_pair_kernel" if L.cin == 256 else "rfd::pw_b2b_kernel")
-    elif o.kind != 2:
+    if o.kind not in (2, 3, 6):
         continue
-    else:
-        k = conv_class(o, L, n_out)
+    k = op_class(i).replace("conv_b2b_s1_persistent_k128_kernel", "conv_b2b_s1_kernel").replace("conv_b2b_s1_persistent_kernel", "conv_b2b_s1_kernel")
     rd = tbytes(o.in_, max(L.cin, 64) if (o.kind == 2 and g.tensors[o.in_].channels > max(L.cin, 64)) else None) + tbytes(o.in2) + tbytes(o.res)
     wr = 0
     for t in (o.out, o.out2, o.outf, o.out_b):
