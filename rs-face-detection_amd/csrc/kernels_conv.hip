@@ -3094,6 +3094,162 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
     }
 }
 
+// PERSISTENT form (round 4): a workgroup walks a contiguous run of tiles.  The 28 weight fragments and the bias stay in registers
+// across tiles (the one-tile kernel re-reads 28 KiB of weights from L2 per 64 pooled pixels), and the NEXT tile's input patch is
+// requested into registers before the conv phase and written to LDS behind it, so its latency hides under the MFMAs instead of
+// opening every tile.  Same arithmetic per tile: bit-identical output.
+__global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__restrict__ x4, const bf16_t *__restrict__ w,
+                                                              const float *__restrict__ bias, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, bf16_t *__restrict__ y, int H,
+                                                              int W, int tiles_w, int tiles_h, int ntiles, int per)
+{
+    __shared__ __attribute__((aligned(16))) uint2 in_tile[kStemIR * kStemIP];
+    __shared__ __attribute__((aligned(16))) bf16_t conv_tile[kStemCR * kStemCC * kStemCP];
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    // scalar wave index: the loops over `wave` below are then scalar loops in the ISA, i.e. their 128-bit LDS reads provably
+    // run with EXEC all ones (tools/isa_check.py, tests/test_build_cpu.py)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = H >> 1, Wo = W >> 1, Hp = Ho >> 1, Wp = Wo >> 1;
+    const int t_begin = (int)blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    if (t_begin >= t_end) return;
+    constexpr int NR = (kStemIR * kStemIP + 255) / 256; // patch elements per thread
+    // patch of tile t: global loads into registers (zero outside the image); written to LDS by store_patch
+    auto load_patch = [&](int t, uint2 (&pre)[NR]) {
+        const int tw_ = t % tiles_w, th_ = (t / tiles_w) % tiles_h, b_ = t / (tiles_w * tiles_h);
+        const int ir0_ = 2 * (2 * th_ * kStemPH - 1) - 3, ic0_ = 2 * (2 * tw_ * kStemPW - 1) - 3;
+        const uint2 *src_ = reinterpret_cast<const uint2 *>(x4) + (size_t)b_ * H * W;
+#pragma unroll
+        for (int round = 0; round < NR; ++round) {
+            const int i = tid + round * 256;
+            const int r = i / kStemIP, c = i - r * kStemIP;
+            const int gr = ir0_ + r, gc = ic0_ + c;
+            // unconditional load from a clamped address, zeroed by a mask: a load under a per-element condition makes hipcc branch
+            // around each one and wait for it there (cdna_hip_programming.md section 5, trap 4(c)) -- seven serialised round trips
+            const bool ok = c < kStemIC && (unsigned)gr < (unsigned)H && (unsigned)gc < (unsigned)W;
+            const uint32_t keep = ok ? 0xffffffffu : 0u;
+            const uint2 v = src_[ok ? (size_t)gr * W + gc : (size_t)0];
+            pre[round] = make_uint2(v.x & keep, v.y & keep);
+        }
+    };
+    auto store_patch = [&](const uint2 (&pre)[NR]) {
+#pragma unroll
+        for (int round = 0; round < NR; ++round) {
+            const int i = tid + round * 256;
+            if (i < kStemIR * kStemIP) in_tile[i] = pre[round];
+        }
+    };
+
+    // weights: 64 x [7][32] resident in registers; A-operand row rho = i*16 + frow holds output channel
+    // (i>>1)*32 + (frow>>2)*8 + (i&1)*4 + (frow&3), so a lane's accumulators are 8 consecutive channels
+    bf16x8 af[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int chn = (i >> 1) * 32 + (frow >> 2) * 8 + (i & 1) * 4 + (frow & 3);
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            af[i][k] = *reinterpret_cast<const bf16x8 *>(w + ((size_t)chn * 7 + k) * 32 + fq * 8);
+    }
+    uint2 pre[NR];
+    load_patch(t_begin, pre);
+    store_patch(pre);
+    __syncthreads();
+
+    float bv[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + h * 32 + fq * 8);
+        const float4 b1 = *reinterpret_cast<const float4 *>(bias + h * 32 + fq * 8 + 4);
+        bv[h][0] = b0.x; bv[h][1] = b0.y; bv[h][2] = b0.z; bv[h][3] = b0.w;
+        bv[h][4] = b1.x; bv[h][5] = b1.y; bv[h][6] = b1.z; bv[h][7] = b1.w;
+    }
+    constexpr int NPIX = kStemCR * kStemCC, NT16 = (NPIX + 15) / 16;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, b = tile / (tiles_w * tiles_h);
+        const int ph0 = th * kStemPH, pw0 = tw * kStemPW;
+        const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1; // first conv pixel
+        const bool more = tile + 1 < t_end;               // workgroup-uniform
+        if (more) load_patch(tile + 1, pre);              // in flight under the conv phase
+    for (int t = wave; t < NT16; t += 4) {
+        const int idx = min(t * 16 + frow, NPIX - 1);
+        const int cr = idx / kStemCC, cc = idx - cr * kStemCC;
+        const uint2 *ip = in_tile + (2 * cr) * kStemIP + 2 * cc + 2 * fq; // 16-byte aligned: even pixel index
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(ip + k * kStemIP);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][k], bf, acc[i], 0, 0, 0);
+        }
+        if (t * 16 + frow < NPIX) {
+            const int gr = cr0 + cr, gc = cc0 + cc;
+            // out-of-image conv pixels become +0 by masking the packed bits (a select per value compiled into a branch each)
+            const uint32_t inside = ((unsigned)gr < (unsigned)Ho && (unsigned)gc < (unsigned)Wo) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = fmaxf(acc[2 * h][k] + bv[h][k], 0.f);
+                    o[4 + k] = fmaxf(acc[2 * h + 1][k] + bv[h][4 + k], 0.f);
+                }
+                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                *reinterpret_cast<uint4 *>(conv_tile + idx * kStemCP + h * 32 + fq * 8) =
+                    make_uint4(lo.x & inside, lo.y & inside, hi.x & inside, hi.y & inside);
+            }
+        }
+    }
+        __syncthreads();                                  // conv tile complete; nobody reads the input patch any more
+        if (more) store_patch(pre);
+    // 3x3/2 max pool over the conv tile, then affine + ReLU; 8 channels (16 bytes) per item
+    static_assert(kStemPH * kStemPW * 8 % 256 == 0, "the pooling pass runs whole rounds of the workgroup (a scalar trip count)");
+    for (int round = 0; round < kStemPH * kStemPW * 8 / 256; ++round) {
+        const int item = tid + round * 256;
+        const int c8 = item & 7, pp = item >> 3;
+        const int pr = pp / kStemPW, pc = pp - pr * kStemPW;
+        // no early `continue`: the ds_read_b128 below must run with EXEC all ones ("a hardware
+        // observation": 128-bit LDS reads under a partial EXEC mask return wrong data in lanes 48-63 while MFMA waves of
+        // another kernel share the CU); only the store is predicated
+        const bool live = ph0 + pr < Hp && pw0 + pc < Wp;
+        // The conv tile holds ReLU outputs: non-negative bf16 (or -0), whose bit patterns order like signed 16-bit integers
+        // (-0 = 0x8000 is the smallest and loses against the initial +0, as it does in float).  So the 3x3 max runs on packed
+        // 16-bit integers, two channels per instruction, and only the result is widened: 36 instead of 144 VALU operations.
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
+        i16x2 mi[4] = {i16x2{0, 0}, i16x2{0, 0}, i16x2{0, 0}, i16x2{0, 0}};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(conv_tile + ((2 * pr + dy) * kStemCC + 2 * pc + dx) * kStemCP + c8 * 8);
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mi[k] = __builtin_elementwise_max(mi[k], __builtin_bit_cast(i16x2, u[k]));
+            }
+        // pin the reads above the `if (live)`: hipcc otherwise sinks the whole body, reads included, under the store's predicate
+        // (seen in the round-3 ISA audit, tools/isa_check.py) -- a volatile asm cannot move into a conditional block
+        asm volatile("" : "+v"(mi[0]), "+v"(mi[1]), "+v"(mi[2]), "+v"(mi[3]));
+        float mx[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = __builtin_bit_cast(uint32_t, mi[k]);
+            mx[2 * k] = bf16_bits_to_f32(u & 0xffffu);
+            mx[2 * k + 1] = bf16_bits_to_f32(u >> 16);
+        }
+        const float4 s0 = *reinterpret_cast<const float4 *>(scale + c8 * 8), s1 = *reinterpret_cast<const float4 *>(scale + c8 * 8 + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(shift + c8 * 8), t1 = *reinterpret_cast<const float4 *>(shift + c8 * 8 + 4);
+        const uint2 lo = pack_bf16x4(fmaxf(mx[0] * s0.x + t0.x, 0.f), fmaxf(mx[1] * s0.y + t0.y, 0.f),
+                                     fmaxf(mx[2] * s0.z + t0.z, 0.f), fmaxf(mx[3] * s0.w + t0.w, 0.f));
+        const uint2 hi = pack_bf16x4(fmaxf(mx[4] * s1.x + t1.x, 0.f), fmaxf(mx[5] * s1.y + t1.y, 0.f),
+                                     fmaxf(mx[6] * s1.z + t1.z, 0.f), fmaxf(mx[7] * s1.w + t1.w, 0.f));
+        if (live) *reinterpret_cast<uint4 *>(y + (((size_t)b * Hp + ph0 + pr) * Wp + pw0 + pc) * 64 + c8 * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+        __syncthreads();                                  // next patch in LDS, conv tile free
+    }
+}
+
+
 int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const float *scale, const float *shift,
                 bf16_t *y, int B, int H, int W, hipStream_t s)
 {
@@ -3103,8 +3259,20 @@ int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const floa
     }
     const int Hp = H / 4, Wp = W / 4;
     const int tiles_h = ceil_div(Hp, kStemPH), tiles_w = ceil_div(Wp, kStemPW);
+    const int ntiles = B * tiles_h * tiles_w;
+    // persistent form from 4 tiles per workgroup slot (2 workgroups per CU by LDS): weights stay in registers, the next patch is
+    // prefetched (RFD_STEM_PERSIST=0: the one-tile kernel, for A/B; bit-identical)
+    static const int persist_env = [] { const char *e = getenv("RFD_STEM_PERSIST"); return e ? atoi(e) : 1; }();
+    const int slots = 2 * device_cus();
+    if (persist_env && ntiles >= 4 * slots) {
+        const int per = ceil_div(ntiles, slots), grid = ceil_div(ntiles, per);
+        if (note_launch("stem_persistent_kernel")) return RFD_OK;
+        hipLaunchKernelGGL(stem_persistent_kernel, dim3((unsigned)grid), dim3(256), 0, s, x4, w, bias, scale, shift, y, H, W, tiles_w, tiles_h, ntiles, per);
+        RFD_HIP(hipGetLastError());
+        return RFD_OK;
+    }
     if (note_launch("stem_kernel")) return RFD_OK;
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(B * tiles_h * tiles_w)), dim3(256), 0, s, x4, w, bias, scale, shift, y,
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, x4, w, bias, scale, shift, y,
                        H, W, tiles_w, tiles_h);
     RFD_HIP(hipGetLastError());
     return RFD_OK;
