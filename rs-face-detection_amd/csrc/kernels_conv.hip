@@ -284,6 +284,44 @@ __device__ __forceinline__ void lds_table_read8(const float *tab, float (&v)[8])
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
 }
 
+// Two / three tables at once behind ONE wait (round 4): the epilogues of the pointwise kernels read bias, scale and shift for the
+// same eight channels; as three lds_table_read8 calls that was three serialised LDS round trips per 8-channel group with every
+// wave of the workgroup in its epilogue at the same time (nothing else running on the CU): one round trip now.
+__device__ __forceinline__ void lds_table_read8x2(const float *t0, const float *t1, float (&a)[8], float (&b)[8])
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 r[8];
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:8\n\tds_read_b64 %6, %9 offset:16\n\tds_read_b64 %7, %9 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"((uint32_t)(uintptr_t)t0), "v"((uint32_t)(uintptr_t)t1)
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[2 * k] = r[k].x; a[2 * k + 1] = r[k].y; b[2 * k] = r[4 + k].x; b[2 * k + 1] = r[4 + k].y; }
+}
+__device__ __forceinline__ void lds_table_read8x3(const float *t0, const float *t1, const float *t2, float (&a)[8], float (&b)[8], float (&c)[8])
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 r[12];
+    asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:8\n\tds_read_b64 %2, %12 offset:16\n\tds_read_b64 %3, %12 offset:24\n\t"
+                 "ds_read_b64 %4, %13\n\tds_read_b64 %5, %13 offset:8\n\tds_read_b64 %6, %13 offset:16\n\tds_read_b64 %7, %13 offset:24\n\t"
+                 "ds_read_b64 %8, %14\n\tds_read_b64 %9, %14 offset:8\n\tds_read_b64 %10, %14 offset:16\n\tds_read_b64 %11, %14 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+                   "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11])
+                 : "v"((uint32_t)(uintptr_t)t0), "v"((uint32_t)(uintptr_t)t1), "v"((uint32_t)(uintptr_t)t2)
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[2 * k] = r[k].x; a[2 * k + 1] = r[k].y;
+        b[2 * k] = r[4 + k].x; b[2 * k + 1] = r[4 + k].y;
+        c[2 * k] = r[8 + k].x; c[2 * k + 1] = r[8 + k].y;
+    }
+}
+
 template <int NK, bool HAS_Y, bool HAS_Y2>
 __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 {
@@ -415,11 +453,8 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
             for (int h = 0; h < 2; ++h) {
                 const int n = n0 + wn * 64 + h * 32 + fq * 8;
                 float bias[8], s2[8], t2[8];
-                lds_table_read8(Tab + n, bias);
-                if (HAS_Y2) {
-                    lds_table_read8(Tab + N + n, s2);
-                    lds_table_read8(Tab + 2 * N + n, t2);
-                }
+                if (HAS_Y2) lds_table_read8x3(Tab + n, Tab + N + n, Tab + 2 * N + n, bias, s2, t2);
+                else lds_table_read8(Tab + n, bias);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int m = m0 + wm * 32 + j * 16 + frow;
@@ -618,9 +653,7 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
             for (int h = 0; h < 2; ++h) {
                 const int n = n0 + wn * 64 + h * 32 + fq * 8;
                 float bias[8], sc[8], sh[8];
-                lds_table_read8(Tab + n, bias);
-                lds_table_read8(Tab + N + n, sc);
-                lds_table_read8(Tab + 2 * N + n, sh);
+                lds_table_read8x3(Tab + n, Tab + N + n, Tab + 2 * N + n, bias, sc, sh);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int row = wm * 32 + j * 16 + frow, m = m0 + row;
@@ -858,9 +891,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int h = 0; h < 4; ++h) {
                 const int n = (nc << 7) + h * 32 + fq * 8;
                 float bias[8], sc[8], sh[8];
-                lds_table_read8(Tab + n, bias);
-                lds_table_read8(Tab + N + n, sc);
-                lds_table_read8(Tab + 2 * N + n, sh);
+                lds_table_read8x3(Tab + n, Tab + N + n, Tab + 2 * N + n, bias, sc, sh);
                 const uint32_t off = m < M ? (uint32_t)(((size_t)m * N + n) * 2) : kOob;
                 const u32x4 rv = cur[h];
                 float v[8];
@@ -1791,8 +1822,7 @@ __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int ti
                 // 8-channel chunk tid & 7 of rows (tid >> 3) + 64 i: one table read per step, 1 KiB contiguous per wave access.
                 const int cch = tid & 7, r0 = tid >> 3;
                 float ss[8], tt[8];
-                lds_table_read8(Sc + k * 64 + cch * 8, ss);
-                lds_table_read8(Sc + K + k * 64 + cch * 8, tt);
+                lds_table_read8x2(Sc + k * 64 + cch * 8, Sc + K + k * 64 + cch * 8, ss, tt);
                 bf16_t *xt = Xs + xs * XEL + r0 * 64 + ((cch ^ (r0 & 7)) << 3);
 #pragma unroll
                 for (int i = 0; i < BM / 64; ++i) {
@@ -2070,11 +2100,8 @@ __global__ void __launch_bounds__(512) pw_wide_kernel(const ConvParams p, int n_
                     }
                 }
                 float bias[8], s2[8], t2[8];
-                lds_table_read8(Tab + ch0, bias);
-                if (p.y2) {
-                    lds_table_read8(Tab + p.Cout + ch0, s2);
-                    lds_table_read8(Tab + 2 * p.Cout + ch0, t2);
-                }
+                if (p.y2) lds_table_read8x3(Tab + ch0, Tab + p.Cout + ch0, Tab + 2 * p.Cout + ch0, bias, s2, t2);
+                else lds_table_read8(Tab + ch0, bias);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = m0 + wm * 64 + j * 16 + frow_;
@@ -2418,9 +2445,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_kernel(const B2BPa
         for (int h = 0; h < 2; ++h) {
             const int n = wn * 64 + h * 32 + fq * 8;
             float bias[8], s2[8], t2[8];
-            lds_table_read8(Tab + n, bias);
-            lds_table_read8(Tab + N1 + n, s2);
-            lds_table_read8(Tab + 2 * N1 + n, t2);
+            lds_table_read8x3(Tab + n, Tab + N1 + n, Tab + 2 * N1 + n, bias, s2, t2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = wm * 64 + j * 16 + frow, m = m0 + row;
@@ -2576,9 +2601,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_k128_kernel(const 
         {
             const int n = wave * 32 + fq * 8; // this lane's 8 consecutive channels
             float bias[8], s2[8], t2[8];
-            lds_table_read8(Tab + n, bias);
-            lds_table_read8(Tab + N1 + n, s2);
-            lds_table_read8(Tab + 2 * N1 + n, t2);
+            lds_table_read8x3(Tab + n, Tab + N1 + n, Tab + 2 * N1 + n, bias, s2, t2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = j * 16 + frow, m = m0 + row;
