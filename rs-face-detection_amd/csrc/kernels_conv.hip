@@ -746,9 +746,29 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 // stream order; after that there is no weight traffic, no ring and therefore no barrier: every wave is an independent pipeline over
 // its 16 pixels.  These kernels are bound by the bytes a CU can pull through its vector-memory path (~25 GB/s per CU, L2-served
 // weight steps included: 272 KiB per tile streaming, 176 KiB resident).
+#ifdef RFD_PAIR_STAMPS // diagnostic build (tools/build_variant.sh ... -DRFD_PAIR_STAMPS): where a wave's cycles go, summed over the grid
+__device__ unsigned long long g_pair_prof[4096 * 10]; // [workgroup * 8 + wave][phase]: plain stores, no atomics
+#define RFD_STAMP(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); prof[i] += t__ - tlast; tlast = t__; } while (0)
+extern "C" __attribute__((visibility("default"))) int rfd_debug_pair_prof(unsigned long long *out, int reset)
+{
+    static unsigned long long host[4096 * 10];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pair_prof), sizeof host) != hipSuccess) return -1;
+    for (int i = 0; i < 10; ++i) out[i] = 0;
+    for (int w = 0; w < 4096; ++w)
+        for (int i = 0; i < 10; ++i) out[i] += host[w * 10 + i];
+    if (reset) { memset(host, 0, sizeof host); if (hipMemcpyToSymbol(HIP_SYMBOL(g_pair_prof), host, sizeof host) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define RFD_STAMP(i) do { } while (0)
+#endif
 template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0>
 __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
 {
+#ifdef RFD_PAIR_STAMPS
+    unsigned long long prof[10] = {}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
     constexpr bool RESIDENT = NCR > 0;
     constexpr int BM = 128, NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : S + 1, N1 = 128 * N1B;
     constexpr bool HAS_RES = NK2 == 0;
@@ -861,9 +881,12 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) { // conv3 (+ shortcut) steps: all 128 rows of the slot against this wave's 16 pixels
+                RFD_STAMP(2);
                 if (!RESIDENT) {
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    RFD_STAMP(0);
                     issue_w();
+                    RFD_STAMP(1);
                 }
                 const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
                 cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
@@ -878,12 +901,14 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
                     }
                 }
             }
+            RFD_STAMP(2);
             // the next tile's activation fragments may be requested as soon as this tile's last conv3 step has read them
             if (last_chunk) issue_x(mt + (int)gridDim.x);
             // ---- the one drain of the chunk: residual of this chunk, W1 steps of this chunk, stores of the previous one ----
             if (HAS_RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             __builtin_amdgcn_sched_barrier(0);
+            RFD_STAMP(3);
             if (!last_chunk) issue_res(nxt, mt, nc + 1);
             else issue_res(nxt, mt + (int)gridDim.x, 0);
             u32x4 actq[4]; // conv1's B fragments: the activated chunk, K slice h = channels h*32 + fq*8 .. +7 of this pixel
@@ -932,9 +957,12 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int k1 = 0; k1 < 2; ++k1)       // conv1: the chunk's 64-channel half k1 ...
 #pragma unroll
                 for (int r1 = 0; r1 < N1B; ++r1) { // ... against the 128-row block r1 of W1 (one slot-step)
+                    RFD_STAMP(k1 == 0 && r1 == 0 ? 4 : 7);
                     if (!RESIDENT) {
                         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        RFD_STAMP(5);
                         issue_w();
+                        RFD_STAMP(6);
                     }
                     const bf16_t *ws = Ws + cslot * 128 * 64 + arow;
                     cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
@@ -952,7 +980,9 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
         };
         for (int nc = 0; nc < NC; nc += 2) {
             do_chunk(nc, resA, resB, false);
+            RFD_STAMP(7);
             do_chunk(nc + 1, resB, resA, nc + 2 >= NC);
+            RFD_STAMP(7);
         }
         // ---- conv1 epilogue: t1 = relu(acc1 + bias1): per 128-row block four 8-channel groups of this pixel ----
 #pragma unroll
@@ -972,7 +1002,16 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rt1, m < M ? (uint32_t)(((size_t)m * N1 + n) * 2) : kOob, 0, 0);
             }
     }
+#ifdef RFD_PAIR_STAMPS
+    RFD_STAMP(4); // the last tile's conv1 epilogue counts as epilogue
+#endif
     wait_vmcnt<0>(); // weight steps, residual and activation loads issued beyond the end
+#ifdef RFD_PAIR_STAMPS
+    RFD_STAMP(8);
+    prof[9] = __builtin_readcyclecounter() - tstart;
+    if (lane == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 10; ++i) g_pair_prof[(blockIdx.x * 8 + wave) * 10 + i] = prof[i];
+#endif
 }
 
 // CU count of the current device, queried once per device (every persistent launcher sizes its "even share, no tail" grid
