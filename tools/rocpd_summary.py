@@ -14,9 +14,9 @@ import sqlite3
 import statistics
 import sys
 
-NET = ("conv_igemm_kernel", "conv3x3_kx_kernel", "conv_b2b_s1_", "stem_kernel", "pw_stream_kernel", "conv3x3_c64_kernel",
-       "conv3x3_halo_kernel", "pw_gemm_kernel", "pw_wide_kernel", "pw_b2b_kernel", "pw_pair_kernel",
-       "conv_tile256_kernel")
+NET = ("conv_igemm_kernel", "conv3x3_kx_kernel", "conv_b2b_s1_", "stem_kernel", "stem_persistent_kernel", "pw_stream_kernel",
+       "conv3x3_c64_kernel", "conv3x3_halo_kernel", "pw_gemm_kernel", "pw_wide_kernel", "pw_b2b_kernel", "pw_pair_kernel",
+       "conv_ring_kernel", "conv_tile256_kernel")   # every network kernel of csrc/kernels_conv.hip + kernels_ring.hip
 
 
 def is_net(name):

@@ -39,7 +39,7 @@ for i, us in times.items():
     o = g.ops[i]
     L = g.layers[o.layer]
     n_out = L.cout + (g.layers[o.layer_n2].cout if o.layer_n2 >= 0 else 0)
-    rd = tb(o.in_, max(L.cin, 64) if g.tensors[o.in_].channels > max(L.cin, 64) else None) + tb(o.in2) + tb(o.res)
+    rd = tb(o.in_, max(L.cin, 64) if g.tensors[o.in_].channels > max(L.cin, 64) else None) + (tb(o.in2) // (g.layers[o.layer2].stride ** 2) if o.layer2 >= 0 else 0) + tb(o.res)  # a stride-2 shortcut reads a quarter of its input
     wr = sum(tb(t, n_out if (t == o.out and g.tensors[t].channels > n_out) else None) for t in (o.out, o.out2, o.outf, o.out_b) if t >= 0)
     t_mfma = 2.0 * o.macs * B / 2.5e15 * 1e6
     t_hbm = (rd + wr) / 5.0e12 * 1e6

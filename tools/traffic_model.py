@@ -40,7 +40,7 @@ for i, o in enumerate(g.ops):
     if o.kind not in (2, 3, 6):
         continue
     k = op_class(i).replace("conv_b2b_s1_persistent_k128_kernel", "conv_b2b_s1_kernel").replace("conv_b2b_s1_persistent_kernel", "conv_b2b_s1_kernel")
-    rd = tbytes(o.in_, max(L.cin, 64) if (o.kind == 2 and g.tensors[o.in_].channels > max(L.cin, 64)) else None) + tbytes(o.in2) + tbytes(o.res)
+    rd = tbytes(o.in_, max(L.cin, 64) if (o.kind == 2 and g.tensors[o.in_].channels > max(L.cin, 64)) else None) + (tbytes(o.in2) // (g.layers[o.layer2].stride ** 2) if o.layer2 >= 0 else 0) + tbytes(o.res)  # a stride-2 shortcut reads every other pixel of every other row
     wr = 0
     for t in (o.out, o.out2, o.outf, o.out_b):
         if t >= 0:
