@@ -744,8 +744,13 @@ __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 // steps whose activation fragments are gathered from x2 at (2 ho, 2 wo)), its bias is added to conv3's, and there is no residual.
 // RESIDENT (NCR = number of chunks, > 0): both filter banks fit LDS (stage 1 -> 2 boundary: 32 + 64 KiB) and are staged ONCE, in
 // stream order; after that there is no weight traffic, no ring and therefore no barrier: every wave is an independent pipeline over
-// its 16 pixels.  These kernels are bound by the bytes a CU can pull through its vector-memory path (~25 GB/s per CU, L2-served
-// weight steps included: 272 KiB per tile streaming, 176 KiB resident).
+// its 16 pixels.
+// What bounds the pair kernels (round 4, corrected): NOT the CU's load path -- tools/ring_fill_bench.hip measures 95-125 GB/s per CU
+// for L2-served tiles even with a single 16-KiB step in flight, where round 3 had read the kernels' 25 GB/s per CU as a ceiling.
+// Phase stamps (-DRFD_PAIR_STAMPS, tools/pair_stamps.py) on stage 3's <4, 2>: fragment reads + MFMAs 46 % of a wave's lifetime
+// (600-1000 cycles per 16-MFMA step: two waves share a SIMD's matrix pipe), the chunk epilogues 27 % (VALU: ~9 instructions per
+// output element, every wave in its epilogue at the same time, matrix pipe idle), barriers 16 %, weight-DMA issue 9 %, drains 2 %.
+// PMC: 45 % of wave cycles waiting, MFMA busy 18 %, LDS 22 %, no bank conflicts (profiles/r04_pmc_sq_counters_per_kernel.txt).
 #ifdef RFD_PAIR_STAMPS // diagnostic build (tools/build_variant.sh ... -DRFD_PAIR_STAMPS): where a wave's cycles go, summed over the grid
 __device__ unsigned long long g_pair_prof[4096 * 10]; // [workgroup * 8 + wave][phase]: plain stores, no atomics
 #define RFD_STAMP(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); prof[i] += t__ - tlast; tlast = t__; } while (0)

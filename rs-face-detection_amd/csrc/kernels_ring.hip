@@ -7,23 +7,30 @@
 // changes is who waits for what:
 //
 //   * kernels_conv.hip's tiles drain the vector-memory counter (`s_waitcnt vmcnt(0)`) and pass a workgroup barrier at
-//     EVERY K step, with every wave both loading and computing: exactly one K step (32 KiB per workgroup) is ever in flight,
-//     and with an issued -> landed latency of ~1.1 us that is ~25-30 GB/s per CU (Little's law), 15-16 % MFMA busy.
-//   * here a workgroup is 4 LOADER waves + 4 CONSUMER waves (one of each per SIMD).  Loader waves issue nothing but LDS-DMA
-//     (`buffer_load ... lds`) into a ring of K-step slots and publish a slot behind a COUNTED `s_waitcnt vmcnt(N)` that
-//     leaves the next D steps in flight (sound: loads retire in order, and a loader wave never stores -- the out-of-order
-//     load/store retirement that forced full drains on the persistent kernels cannot occur; tools/isa_check.py enforces it).
-//     Consumer waves wait for a slot's FULL count, read its fragments, bump its FREE count (right behind the reads: LDS
-//     executes a wave's instructions in order) and run the MFMAs.  No workgroup barrier in the K loop.
-//     MI355X_MICROARCH.md, "ring-gemm": L2-served fills reach 66-73 GB/s per CU with ~72 KiB in flight.
+//     EVERY K step, with every wave both loading and computing; one workgroup per CU on these small-M layers, so drain, barrier,
+//     DMA issue, fragment reads and MFMAs follow one another: 1 500-1 700 cycles per step for 512 cycles of MFMA work.
+//   * here a workgroup is 4 LOADER waves + 4 CONSUMER waves (one of each per SIMD: waves w and w + 4 share a SIMD,
+//     tools/wave_placement.hip).  Loader waves issue nothing but LDS-DMA (`buffer_load ... lds`) into a ring of K-step slots and
+//     publish a slot behind a COUNTED `s_waitcnt vmcnt(N)` that leaves the next D steps in flight (sound: operations retire in
+//     issue order per wave, and a loader wave never stores -- tools/isa_check.py enforces it).  Consumer waves wait for a slot's
+//     FULL count, read its fragments, bump its FREE count (right behind the reads: LDS executes a wave's instructions in order)
+//     and run the MFMAs.  No workgroup barrier in the K loop.
+//   What it buys is bounded (DESIGN_AB_RECORD.md, round 4): a CU's load path takes 95-125 GB/s from L2 even with ONE step in flight
+//   (tools/ring_fill_bench.hip) -- the round-3 review's Little's-law reading of these layers did not hold -- and a 128 x 128 x 64
+//   step moves 32 KiB through that 64-B/clk path for 512 cycles of MFMA work, so the tile is at best half of either roof.  The
+//   ring is 5-10 % faster than the barrier kernels on stage 4's 1x1 and stride-2 layers and slower everywhere else; launch_conv
+//   routes exactly those layers here.
 //
 // Two forms of one template:
-//   generic  one activation tile (128 rows x 128 B) + one weight tile per K step; ring of 4 slots x 32 KiB, 3 steps in flight.
+//   generic  one activation tile (128 rows x 128 B) + one weight tile per K step; ring of 4 slots x 32 KiB, D = 1: one step in
+//            flight behind the one being published, two slots of slack (a loader that fills the LAST free slot waits for a whole
+//            publish -> poll -> read -> FREE -> poll round trip before it can issue again: 0.35 us per step, measured).
 //   KX3      3x3 / stride 1 / pad 1: the three kx taps of a (chunk, ky) share ONE extended activation tile (160 rows) as in
-//            conv3x3_kx_kernel; activation ring 3 x 20 KiB, weight ring 6 x 16 KiB, 5 weight steps in flight.
+//            conv3x3_kx_kernel; activation ring 3 x 20 KiB, weight ring 6 x 16 KiB, D = 2.
 // Flags live in LDS as monotonic counters: FULL[slot] += 1 per loader wave per fill, FREE[slot] += 1 per consumer wave per
 // use; fill r of a slot waits for FREE >= 4 r, use r waits for FULL >= 4 (r + 1).  Every spin is bounded: a wave that gives
-// up sets *p.fail (read back by the host as RFD_ERR_HIP -- wrong detections are never returned) and stops waiting.
+// up marks an LDS word, the consumer waves copy it to *p.fail (read back by the host as RFD_ERR_HIP -- wrong detections are never
+// returned), and it stops waiting.
 #include <type_traits>
 
 #include "conv_device.h"
