@@ -199,6 +199,7 @@ struct rfd_ctx {
     DevBuf staging, imgs, in4, rows, keys, sorted_keys, sorted_boxes, count, det_scale;
     DevBuf nms_kept, nms_state; // chunked NMS (dense crowds): kept-box lists, per-chunk {count, epoch} + the spin_fail word
     int nms_epoch = 0;
+    int nms_ticket_sel = 0;  // which of the two chunk-ticket counters the next chunked NMS launch draws from
     bool nms_chunked = true; // RFD_NMS_CHUNKED=0: one workgroup per image always (A/B and fallback)
     // host mirror (page-locked) of the chunked NMS's spin_fail word: copied stream-ordered behind every NMS launch, looked at
     // wherever the host synchronises with the stream (check_nms_flag)
@@ -377,11 +378,14 @@ int post_network(rfd_ctx *c, DecodeParams &dp, bool nchw, int n, float *oboxes, 
         np.kept_boxes = (float4 *)c->nms_kept.p;
         np.chunk_state = (int *)c->nms_state.p;
         np.spin_fail = (int *)c->nms_state.p + (size_t)c->cfg.max_batch_size * kNmsChunks * 2;
-        np.ticket = (unsigned long long *)(np.spin_fail + 2);
+        np.ticket = (unsigned *)(np.spin_fail + 2);
+        np.ticket_sel = c->nms_ticket_sel;
         c->nms_epoch = c->nms_epoch == 0x7fffffff ? 1 : c->nms_epoch + 1;
         np.epoch = c->nms_epoch;
     }
-    RFD_TRY(launch_nms(np, n, c->stream));
+    bool used_chunked = false;
+    RFD_TRY(launch_nms(np, n, c->stream, &used_chunked));
+    if (used_chunked) c->nms_ticket_sel ^= 1; // that launch leaves its counter at the grid size and zeroes the other one
     RFD_HIP(hipEventRecord(c->ev[6], c->stream));
     // the device word is sticky (the kernel only ever sets it), so a later call's copy cannot hide an earlier give-up
     // (copied whether or not the chunked kernel ran: the ring convolutions of the network pass report into the same word)

@@ -66,11 +66,12 @@ struct NmsParams {
     float4 *kept_boxes;          // [n][total_anchors] scratch: the kept boxes of an image in score order, chunk after chunk
     int *chunk_state;            // [n][kNmsChunks][2]: {kept count, epoch of the launch that published it}; zero-initialised once
     int *spin_fail;              // set to 1 if a chunk gave up waiting for its predecessor (bounded spin; never expected)
-    unsigned long long *ticket;  // {epoch : 32 | next chunk id : 32}: workgroups draw their (image, chunk) in the order they start
+    unsigned *ticket;            // two counters: workgroups draw their (image, chunk) from ticket[ticket_sel] in the order they start
+    int ticket_sel;              // 0 / 1, alternating between the launches of a context (the idle counter is zeroed by ticket 0)
     int epoch;                   // > 0, different for every launch that uses chunk_state
 };
 constexpr int kNmsChunks = 4;
-int launch_nms(NmsParams p, int n_images, hipStream_t s);
+int launch_nms(NmsParams p, int n_images, hipStream_t s, bool *used_chunked = nullptr);
 
 // FaceSelection::call on the device (face_selection.rs:72-189): per image, over its kept detections
 struct SelectParams {
