@@ -767,15 +767,24 @@ extern "C" __attribute__((visibility("default"))) int rfd_debug_pair_prof(unsign
 #else
 #define RFD_STAMP(i) do { } while (0)
 #endif
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0>
-__global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
+// NW (round 4): waves per workgroup.  8 = the form above (128-pixel tiles, one workgroup per CU, the weight stream a whole chunk
+// ahead in an S + 1 slot ring, one drain per chunk).  4 = HALF workgroups: 64-pixel tiles, a 2-slot weight ring with the next
+// step issued one step ahead and drained at the top of every step (conv_igemm's scheme: the L2-served 16-KiB step lands in
+// ~170 ns, tools/ring_fill_bench.hip), 45 KiB of LDS -- so TWO workgroups share a CU and run out of phase: one's chunk epilogue
+// (VALU, 27 % of a wave's lifetime with the matrix pipe idle) and barrier stalls fall under the other's MFMA steps.  Each wave
+// still owns 16 pixels with the same arithmetic in the same order: bit-identical.
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p) // 2 waves per SIMD: 256 registers, so two half workgroups fit a CU
 {
 #ifdef RFD_PAIR_STAMPS
     unsigned long long prof[10] = {}, tlast = __builtin_readcyclecounter();
     const unsigned long long tstart = tlast;
 #endif
     constexpr bool RESIDENT = NCR > 0;
-    constexpr int BM = 128, NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : S + 1, N1 = 128 * N1B;
+    constexpr bool SHORT = NW == 4; // 2-slot ring, one step of lead, a drain per step
+    static_assert(NW == 8 || (NW == 4 && !RESIDENT), "8 waves, or 4 with the short ring");
+    constexpr int BM = 16 * NW, NT = 64 * NW, PQ = 16 / NW; // pixels per tile, threads, weight pieces per wave and step
+    constexpr int NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : (SHORT ? 2 : S + 1), N1 = 128 * N1B;
     constexpr bool HAS_RES = NK2 == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Ws = reinterpret_cast<bf16_t *>(smem);                    // [WSLOTS][128*64]
@@ -789,8 +798,8 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     const int lr = lane >> 3, chunk = (lane & 7) ^ lr, frow = lane & 15, fq = lane >> 4;
     if ((int)blockIdx.x >= tiles_m) return;
 
-    for (int round = 0; round < (N + 511) / 512; ++round) { // scalar trip count, predicated body
-        const int c = tid + round * 512;
+    for (int round = 0; round < (N + NT - 1) / NT; ++round) { // scalar trip count, predicated body
+        const int c = tid + round * NT;
         if (c < N) {
             Tab[c] = NK2 ? p.bias[c] + p.bias2[c] : p.bias[c]; // conv_epilogue adds the two biases first, then the accumulator
             Tab[N + c] = p.scale2[c];
@@ -807,10 +816,10 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     const u32x4 rres = make_srd(p.res, (uint32_t)((size_t)M * N * 2));
     const u32x4 rxs = make_srd(p.x, (uint32_t)((size_t)M * K * 2));
     const u32x4 rxs2 = make_srd(NK2 ? p.x2 : p.x, (uint32_t)(NK2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0));
-    uint32_t woff[2], woff1[2];
+    uint32_t woff[PQ], woff1[PQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int rho = (wave + 8 * q) * 8 + lr;
+    for (int q = 0; q < PQ; ++q) {
+        const int rho = (wave + NW * q) * 8 + lr;
         const int rw_ = rho & 63, i_ = rw_ >> 4, fq_ = (rw_ >> 2) & 3, r_ = rw_ & 3;
         const int chn = (rho - rw_) + (i_ >> 1) * 32 + fq_ * 8 + (i_ & 1) * 4 + r_;
         woff[q] = (uint32_t)(((size_t)chn * KT + chunk * 8) * 2);
@@ -826,7 +835,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
         const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * KT + (wi_s << 6)) * 2)
                                : w1_delta + (uint32_t)((((size_t)r1 * 128) * N + (wi_nc << 7) + (k1 << 6)) * 2);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + 8 * q) * 512);
+        for (int q = 0; q < PQ; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + NW * q) * 512);
         if (++wi_s == S) { wi_s = 0; if (++wi_nc == NC) wi_nc = 0; }
         wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
     };
@@ -863,7 +872,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
     issue_res(resA, blockIdx.x, 0);
     if (!RESIDENT) {
 #pragma unroll
-        for (int i = 0; i < S; ++i) issue_w(); // the first chunk's steps
+        for (int i = 0; i < (SHORT ? 1 : S); ++i) issue_w(); // the first chunk's steps (SHORT: the first step)
     }
     int cslot = 0;
     const int arow = frow * 64; // A fragment of row block i: row i*16 + frow; 16-byte slot (kk*4 + fq) ^ (row & 7), row & 7 = frow & 7
@@ -888,6 +897,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
             for (int kt = 0; kt < NKT; ++kt) { // conv3 (+ shortcut) steps: all 128 rows of the slot against this wave's 16 pixels
                 RFD_STAMP(2);
                 if (!RESIDENT) {
+                    if (SHORT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's weights (issued one step ago) and everything older
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     RFD_STAMP(0);
                     issue_w();
@@ -964,6 +974,7 @@ __global__ void __launch_bounds__(512) pw_pair_kernel(const ConvParams p)
                 for (int r1 = 0; r1 < N1B; ++r1) { // ... against the 128-row block r1 of W1 (one slot-step)
                     RFD_STAMP(k1 == 0 && r1 == 0 ? 4 : 7);
                     if (!RESIDENT) {
+                        if (SHORT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         RFD_STAMP(5);
                         issue_w();
@@ -1104,8 +1115,36 @@ template <int NK, bool ACT_OUT> static int launch_pw_b2b(const ConvParams &p, hi
     note_launch("pw_b2b_kernel<%d, %s>", NK, ACT_OUT ? "true" : "false");
     return launch_persistent<pw_b2b_kernel<NK, ACT_OUT>>(grid, lds_need, s, p);
 }
+// half-workgroup form of pw_pair_kernel (NW = 4): two workgroups per CU, 64-pixel tiles, short weight ring
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_half(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = ceil_div(M, 64);
+    const int slots = 2 * persistent_cus(p.co_running, true);
+    const int per = ceil_div(tiles_m, slots);
+    const int grid = ceil_div(tiles_m, per);
+    const size_t lds_need = (size_t)2 * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
+    // each workgroup asks for HALF the CU's LDS, so that exactly two co-reside (and nothing else beside them)
+    constexpr size_t kHalfLds = 80 * 1024;
+    if (lds_need > kHalfLds) { set_error("pw_pair (half workgroups): %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4>", NK, N1B, ACT_OUT ? "true" : "false", NK2);
+    if (launch_note().dry) return RFD_OK;
+    auto kern = pw_pair_kernel<NK, N1B, ACT_OUT, NK2, 0, 4>;
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)kHalfLds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kHalfLds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
 template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
 {
+    // RFD_PAIR_HALF: which pairs run as half workgroups (bit mask: 1 stage 3's middle units <4,2>, 2 the 2 -> 3 boundary <2,2,true>,
+    // 4 stage 2's first unit <2,1,false,4>, 8 stage 2's middle units); A/B knob, bit-identical either way
+    static const int half_env = [] { const char *e = getenv("RFD_PAIR_HALF"); return e ? atoi(e) : 0; }();
+    if (NCR == 0) {
+        const int bit = (NK == 4 && N1B == 2) ? 1 : (NK == 2 && N1B == 2) ? 2 : (NK == 2 && NK2 == 4) ? 4 : (NK == 2 && N1B == 1 && NK2 == 0) ? 8 : 0;
+        if (half_env & bit) return launch_pw_pair_half<NK, N1B, ACT_OUT, NK2>(p, s);
+    }
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
     const int ncu = persistent_cus(p.co_running, true);
