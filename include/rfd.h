@@ -39,7 +39,8 @@ typedef enum rfd_status {
     RFD_OK = 0,
     RFD_ERR_INVALID_ARG = -1, /* null pointer, bad shape, channels != 3 (reference: OpenCV error / at_2d failure, face_detection.rs:137,226) */
     RFD_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at creation */
-    RFD_ERR_HIP = -3,         /* a HIP call or kernel failed (reference: Triton RPC failure, face_detection.rs:282) */
+    RFD_ERR_HIP = -3,         /* a HIP call or kernel failed, or a device-side bounded wait gave up (chunked NMS, ring convolution): the
+                               * detections since the last synchronisation are invalid (reference: Triton RPC failure, face_detection.rs:282) */
     RFD_ERR_CAPACITY = -4,    /* batch / frame / detections exceed the configured capacity */
     RFD_ERR_STATE = -5,       /* weights not initialised (reference: empty model config, face_detection.rs:239) */
     RFD_ERR_IO = -6,          /* weight file could not be read / written */
@@ -71,9 +72,11 @@ typedef struct rfd_config {
     int max_src_h;              /* default 2160 */
     int backbone;               /* rfd_backbone */
     int precision;              /* rfd_precision: 0 = bf16 activations / weights with f32 accumulation (the product path,
-                                 * BASELINE.json configs[2]); 1 = the f32 parity mode (RetinaFace-R50 only): f32 weights,
-                                 * activations and accumulation, the reference's FP32 tensor contract (face_detection.rs:261).
-                                 * A correctness mode: plain FMA kernels, one stream, ~20x slower than the bf16 path. */
+                                 * BASELINE.json configs[2]); 1 = the f32 parity mode (RetinaFace-R50 only): f32 weights
+                                 * and activations, convolutions accumulated in f64 and rounded once per output -- the reference's
+                                 * FP32 tensor contract (face_detection.rs:261), reproducible to the bit by any evaluation that
+                                 * sums the same products exactly.  A correctness mode: plain FMA kernels, one stream, ~60x slower
+                                 * than the bf16 path. */
     int reserved[5];
 } rfd_config;
 
@@ -355,8 +358,8 @@ RFD_API int rfd_debug_op_kernels(rfd_ctx *ctx, int n, int op, int co_running, ch
 RFD_API int rfd_debug_set_concurrency(rfd_ctx *ctx, int multi_stream, int split_min_part, int split_max_parts,
                                       int use_graph);
 
-/* Sets the device word through which a chunk workgroup of the dense-crowd NMS reports that it gave up waiting for its
- * predecessor (tests: the next call that synchronises must then fail with RFD_ERR_HIP and clear the word). */
+/* Sets the device word through which a chunk workgroup of the dense-crowd NMS -- or a wave of a ring convolution -- reports that
+ * it gave up waiting (tests: the next call that synchronises must then fail with RFD_ERR_HIP and clear the word). */
 RFD_API int rfd_debug_poke_nms_flag(rfd_ctx *ctx, int value);
 /* The list of PERSISTENT kernels (one workgroup per CU, looping over work items) and the dynamic LDS every launch of one
  * requests -- always the CU's whole 160 KiB, so that no other kernel's workgroup can share the CU.
