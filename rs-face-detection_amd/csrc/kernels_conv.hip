@@ -773,17 +773,20 @@ extern "C" __attribute__((visibility("default"))) int rfd_debug_pair_prof(unsign
 // ~170 ns, tools/ring_fill_bench.hip), 45 KiB of LDS -- so TWO workgroups share a CU and run out of phase: one's chunk epilogue
 // (VALU, 27 % of a wave's lifetime with the matrix pipe idle) and barrier stalls fall under the other's MFMA steps.  Each wave
 // still owns 16 pixels with the same arithmetic in the same order: bit-identical.
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8>
-__global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p) // 2 waves per SIMD: 256 registers, so two half workgroups fit a CU
+// PX (round 4): 16-pixel groups per wave.  2 = a wave owns 32 pixels: every weight fragment read from LDS feeds TWO MFMAs (the
+// 16-pixel forms read one fragment per MFMA -- 8 MiB of LDS reads per 128 pixels, as many LDS cycles as the tile has MFMA cycles);
+// 4 waves x 32 pixels, one wave per SIMD with up to 512 registers, the deep ring.
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8, int PX = 1>
+__global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const ConvParams p) // PX 1: 2 waves per SIMD (256 registers: two half workgroups fit a CU)
 {
 #ifdef RFD_PAIR_STAMPS
     unsigned long long prof[10] = {}, tlast = __builtin_readcyclecounter();
     const unsigned long long tstart = tlast;
 #endif
     constexpr bool RESIDENT = NCR > 0;
-    constexpr bool SHORT = NW == 4; // 2-slot ring, one step of lead, a drain per step
-    static_assert(NW == 8 || (NW == 4 && !RESIDENT), "8 waves, or 4 with the short ring");
-    constexpr int BM = 16 * NW, NT = 64 * NW, PQ = 16 / NW; // pixels per tile, threads, weight pieces per wave and step
+    constexpr bool SHORT = NW == 4 && PX == 1; // 2-slot ring, one step of lead, a drain per step
+    static_assert((NW == 8 && PX == 1) || (NW == 4 && !RESIDENT && (PX == 1 || PX == 2)), "8 waves x 16 px, 4 x 16 (short ring) or 4 x 32");
+    constexpr int BM = 16 * NW * PX, NT = 64 * NW, PQ = 16 / NW; // pixels per tile, threads, weight pieces per wave and step
     constexpr int NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : (SHORT ? 2 : S + 1), N1 = 128 * N1B;
     constexpr bool HAS_RES = NK2 == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -840,29 +843,36 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
         wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
     };
     // this lane: pixel row wave*16 + frow of the tile; per chunk its four 8-channel groups h*32 + fq*8 (h = 0..3)
-    auto issue_res = [&](u32x4 (&r)[4], int mt, int nc) {
+    // (pixel group g of the wave: tile rows (wave * PX + g) * 16 + frow)
+    auto issue_res = [&](u32x4 (&r)[PX][4], int mt, int nc) {
         if (!HAS_RES) return;
-        const int m = mt * BM + wave * 16 + frow;
-        const bool ok = mt < tiles_m && m < M;
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-            asm_buffer_load_b128(r[h], ok ? (uint32_t)(((size_t)m * N + (nc << 7) + h * 32 + fq * 8) * 2) : kOob, rres);
+        for (int g = 0; g < PX; ++g) {
+            const int m = mt * BM + (wave * PX + g) * 16 + frow;
+            const bool ok = mt < tiles_m && m < M;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                asm_buffer_load_b128(r[g][h], ok ? (uint32_t)(((size_t)m * N + (nc << 7) + h * 32 + fq * 8) * 2) : kOob, rres);
+        }
     };
-    u32x4 xq[NKT * 2]; // the activation tile of this wave as B fragments: K slice q = channels q*32 + fq*8 .. +7 of pixel `frow`
+    u32x4 xq[PX][NKT * 2]; // the activation tile of this wave as B fragments: K slice q = channels q*32 + fq*8 .. +7 of pixel `frow`
     auto issue_x = [&](int mt) {
-        const int m = mt * BM + wave * 16 + frow;
-        const bool ok = mt < tiles_m && m < M;
 #pragma unroll
-        for (int q = 0; q < NK * 2; ++q) asm_buffer_load_b128(xq[q], ok ? (uint32_t)(((size_t)m * K + q * 32 + fq * 8) * 2) : kOob, rxs);
-        if (NK2) { // the shortcut's source pixel: (b, stride2 * ho, stride2 * wo) of x2
-            const int HoWo = p.Ho * p.Wo, mm = ok ? m : 0, b = mm / HoWo, rem = mm - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const uint32_t base = (uint32_t)(((((size_t)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + fq * 8) * 2);
+        for (int g = 0; g < PX; ++g) {
+            const int m = mt * BM + (wave * PX + g) * 16 + frow;
+            const bool ok = mt < tiles_m && m < M;
 #pragma unroll
-            for (int q = 0; q < NK2 * 2; ++q) asm_buffer_load_b128(xq[NK * 2 + q], ok ? base + (uint32_t)(q * 64) : kOob, rxs2);
+            for (int q = 0; q < NK * 2; ++q) asm_buffer_load_b128(xq[g][q], ok ? (uint32_t)(((size_t)m * K + q * 32 + fq * 8) * 2) : kOob, rxs);
+            if (NK2) { // the shortcut's source pixel: (b, stride2 * ho, stride2 * wo) of x2
+                const int HoWo = p.Ho * p.Wo, mm = ok ? m : 0, b = mm / HoWo, rem = mm - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const uint32_t base = (uint32_t)(((((size_t)b * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + fq * 8) * 2);
+#pragma unroll
+                for (int q = 0; q < NK2 * 2; ++q) asm_buffer_load_b128(xq[g][NK * 2 + q], ok ? base + (uint32_t)(q * 64) : kOob, rxs2);
+            }
         }
     };
 
-    u32x4 resA[4] = {}, resB[4] = {};
+    u32x4 resA[PX][4] = {}, resB[PX][4] = {};
     if (RESIDENT) { // the whole of both filter banks, once: NCR chunks x S steps fill the NCR * S slots in consumption order
         for (int i = 0; i < WSLOTS; ++i) issue_w();
         wait_vmcnt<0>();
@@ -878,21 +888,26 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
     const int arow = frow * 64; // A fragment of row block i: row i*16 + frow; 16-byte slot (kk*4 + fq) ^ (row & 7), row & 7 = frow & 7
 
     for (int mt = blockIdx.x; mt < tiles_m; mt += gridDim.x) {
-        const int m = mt * BM + wave * 16 + frow;
-        f32x4 acc1[8 * N1B];
+        f32x4 acc1[PX][8 * N1B];
 #pragma unroll
-        for (int i = 0; i < 8 * N1B; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < PX; ++g)
+#pragma unroll
+            for (int i = 0; i < 8 * N1B; ++i) acc1[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the tile's activation fragments (requested during the previous tile's last chunk, or before the loop) and everything older
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         // ... and xq[] is only defined from here on: tied to the wait as cur[] is below, so that no copy of a fragment register
         // hipcc might make (a phi across the back edge, a spill-free re-allocation) can be taken before the loads have landed
         // (volatile asm statements keep their order; round-3 advisor finding)
 #pragma unroll
-        for (int q = 0; q < NKT * 2; ++q) asm volatile("" : "+v"(xq[q]));
-        auto do_chunk = [&](int nc, u32x4 (&cur)[4], u32x4 (&nxt)[4], bool last_chunk) __attribute__((always_inline)) {
-            f32x4 acc[8];
+        for (int g = 0; g < PX; ++g)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < NKT * 2; ++q) asm volatile("" : "+v"(xq[g][q]));
+        auto do_chunk = [&](int nc, u32x4 (&cur)[PX][4], u32x4 (&nxt)[PX][4], bool last_chunk) __attribute__((always_inline)) {
+            f32x4 acc[PX][8];
+#pragma unroll
+            for (int g = 0; g < PX; ++g)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) { // conv3 (+ shortcut) steps: all 128 rows of the slot against this wave's 16 pixels
                 RFD_STAMP(2);
@@ -907,12 +922,13 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
                 cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, xq[kt * 2 + kk]);
                     const int so = ((kk * 4 + fq) ^ (frow & 7)) << 3;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 1024 + so);
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < PX; ++g) // one fragment read, PX MFMAs
+                            acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, xq[g][kt * 2 + kk]), acc[g][i], 0, 0, 0);
                     }
                 }
             }
@@ -920,25 +936,30 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
             // the next tile's activation fragments may be requested as soon as this tile's last conv3 step has read them
             if (last_chunk) issue_x(mt + (int)gridDim.x);
             // ---- the one drain of the chunk: residual of this chunk, W1 steps of this chunk, stores of the previous one ----
-            if (HAS_RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            if (HAS_RES) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[0][2]), "+v"(cur[0][3]) : : "memory");
+                if (PX == 2) asm volatile("" : "+v"(cur[PX - 1][0]), "+v"(cur[PX - 1][1]), "+v"(cur[PX - 1][2]), "+v"(cur[PX - 1][3])); // behind the wait (volatile asm keeps its order)
+            } else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             __builtin_amdgcn_sched_barrier(0);
             RFD_STAMP(3);
             if (!last_chunk) issue_res(nxt, mt, nc + 1);
             else issue_res(nxt, mt + (int)gridDim.x, 0);
-            u32x4 actq[4]; // conv1's B fragments: the activated chunk, K slice h = channels h*32 + fq*8 .. +7 of this pixel
+            u32x4 actq[PX][4]; // conv1's B fragments: the activated chunk, K slice h = channels h*32 + fq*8 .. +7 of this pixel
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const int n = (nc << 7) + h * 32 + fq * 8;
                 float bias[8], sc[8], sh[8];
                 lds_table_read8x3(Tab + n, Tab + N + n, Tab + 2 * N + n, bias, sc, sh);
+#pragma unroll
+              for (int g = 0; g < PX; ++g) {
+                const int m = mt * BM + (wave * PX + g) * 16 + frow;
                 const uint32_t off = m < M ? (uint32_t)(((size_t)m * N + n) * 2) : kOob;
-                const u32x4 rv = cur[h];
+                const u32x4 rv = cur[g][h];
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[k] = acc[2 * h][k] + bias[k];
-                    v[4 + k] = acc[2 * h + 1][k] + bias[4 + k];
+                    v[k] = acc[g][2 * h][k] + bias[k];
+                    v[4 + k] = acc[g][2 * h + 1][k] + bias[4 + k];
                 }
                 if (HAS_RES) {
 #pragma unroll
@@ -966,7 +987,8 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
                     }
                     alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
                 }
-                actq[h] = u32x4{alo.x, alo.y, ahi.x, ahi.y};
+                actq[g][h] = u32x4{alo.x, alo.y, ahi.x, ahi.y};
+              }
             }
 #pragma unroll
             for (int k1 = 0; k1 < 2; ++k1)       // conv1: the chunk's 64-channel half k1 ...
@@ -984,12 +1006,13 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
                     cslot = cslot + 1 == WSLOTS ? 0 : cslot + 1;
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        const bf16x8 b = __builtin_bit_cast(bf16x8, actq[k1 * 2 + kk]);
                         const int so = ((kk * 4 + fq) ^ (frow & 7)) << 3;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 1024 + so);
-                            acc1[r1 * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1[r1 * 8 + i], 0, 0, 0);
+#pragma unroll
+                            for (int g = 0; g < PX; ++g)
+                                acc1[g][r1 * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, actq[g][k1 * 2 + kk]), acc1[g][r1 * 8 + i], 0, 0, 0);
                         }
                     }
                 }
@@ -1008,14 +1031,18 @@ __global__ void __launch_bounds__(NW * 64, 2) pw_pair_kernel(const ConvParams p)
                 const int n = r1 * 128 + h * 32 + fq * 8;
                 float b1[8];
                 lds_table_read8(Tab + 3 * N + n, b1);
-                float o[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    o[k] = fmaxf(acc1[r1 * 8 + 2 * h][k] + b1[k], 0.f);
-                    o[4 + k] = fmaxf(acc1[r1 * 8 + 2 * h + 1][k] + b1[4 + k], 0.f);
+                for (int g = 0; g < PX; ++g) {
+                    const int m = mt * BM + (wave * PX + g) * 16 + frow;
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[k] = fmaxf(acc1[g][r1 * 8 + 2 * h][k] + b1[k], 0.f);
+                        o[4 + k] = fmaxf(acc1[g][r1 * 8 + 2 * h + 1][k] + b1[4 + k], 0.f);
+                    }
+                    const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rt1, m < M ? (uint32_t)(((size_t)m * N1 + n) * 2) : kOob, 0, 0);
                 }
-                const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, rt1, m < M ? (uint32_t)(((size_t)m * N1 + n) * 2) : kOob, 0, 0);
             }
     }
 #ifdef RFD_PAIR_STAMPS
@@ -1136,6 +1163,25 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }
+// 32-pixel-per-wave form of pw_pair_kernel (NW = 4, PX = 2): 128-pixel tiles, one workgroup of 4 waves per CU, the deep ring
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_px2(const ConvParams &p, hipStream_t s)
+{
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = ceil_div(M, 128);
+    const int ncu = persistent_cus(p.co_running, true);
+    const int per = ceil_div(tiles_m, ncu);
+    const int grid = ceil_div(tiles_m, per);
+    const size_t lds_need = (size_t)(NK + NK2 + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
+    if (lds_need > kPersistentLds) { set_error("pw_pair (32 px per wave): %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4, 2>", NK, N1B, ACT_OUT ? "true" : "false", NK2);
+    if (launch_note().dry) return RFD_OK;
+    auto kern = pw_pair_kernel<NK, N1B, ACT_OUT, NK2, 0, 4, 2>;
+    static DynLdsOnce once;
+    RFD_TRY(once.ensure(reinterpret_cast<const void *>(kern), (int)kPersistentLds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kPersistentLds, s, p);
+    RFD_HIP(hipGetLastError());
+    return RFD_OK;
+}
 template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
 {
     // RFD_PAIR_HALF: which pairs run as half workgroups (bit mask: 1 stage 3's middle units <4,2>, 2 the 2 -> 3 boundary <2,2,true>,
@@ -1144,6 +1190,9 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int la
     if (NCR == 0) {
         const int bit = (NK == 4 && N1B == 2) ? 1 : (NK == 2 && N1B == 2) ? 2 : (NK == 2 && NK2 == 4) ? 4 : (NK == 2 && N1B == 1 && NK2 == 0) ? 8 : 0;
         if (half_env & bit) return launch_pw_pair_half<NK, N1B, ACT_OUT, NK2>(p, s);
+        // RFD_PAIR_PX2: the same bit mask for the 32-pixel-per-wave form
+        static const int px2_env = [] { const char *e = getenv("RFD_PAIR_PX2"); return e ? atoi(e) : 0; }();
+        if (px2_env & bit) return launch_pw_pair_px2<NK, N1B, ACT_OUT, NK2>(p, s);
     }
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = ceil_div(M, 128);
