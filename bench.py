@@ -428,8 +428,9 @@ def main():
                          "traffic_unit": "HBM bytes per forward pass of the network conv kernels (PMC: FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_source,
                          "hbm_frac_of_8TBps": round(traffic / (net_ms_med * 1e-3) / 8e12, 4) if traffic else None,
-                         "kernel": "network conv kernels of one forward pass (conv_igemm / conv3x3_kx / conv3x3_halo / conv3x3_c64 / "
-                                   "pw_stream / pw_gemm / conv_b2b_s1 / stem), timed as a class: the two half-batch chains overlap",
+                         "kernel": "network conv kernels of one forward pass (stem_persistent / conv_igemm / conv_ring / conv3x3_kx / conv3x3_halo / "
+                                   "conv3x3_c64 / pw_stream / pw_gemm / pw_wide / pw_b2b / pw_pair / conv_b2b_s1), timed as a class: the two "
+                                   "half-batch chains overlap",
                          "flops_per_pass": net_flops, "ms_per_pass": round(net_ms_med, 4),
                          "serialised": {"note": "same pass with every op on one stream, HIP events around each of the %d "
                                                 "implicit-GEMM launches (conv0/stem excluded)" % launches,

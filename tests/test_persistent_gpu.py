@@ -181,29 +181,31 @@ def test_forced_persistent_kernels_on_other_input_sizes(rfd, size):
     assert checked >= 60
 
 
-def test_persistent_stem_equals_one_tile_stem_bitwise(rfd):
+@pytest.mark.parametrize("size", [(640, 640), (480, 352)])
+def test_persistent_stem_equals_one_tile_stem_bitwise(rfd, size):
     """The fused stem (conv0 + max pool + BN1) runs as a persistent kernel from 4 tiles per workgroup slot (round 4: weights stay in
     registers, the next tile's input patch is prefetched under the conv phase) and as one workgroup per tile below that.  Same
     arithmetic per tile: 16 frames in one launch (persistent: 6 400 tiles) against the same frames two at a time (800 tiles: the
     one-tile kernel), and a batch whose last workgroup gets a short run of tiles."""
-    det = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=16, max_det=16)
+    nb = 16 if size == (640, 640) else 40      # (480 x 352: 30 x 22 pooled pixels per image -> partial tiles on both edges)
+    det = rfd.RetinaFaceDetection(image_size=size, max_batch_size=nb, max_det=16)
     det.init_synthetic_weights(1234)
-    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    g = rfd.Graph(rfd.BACKBONE_R50, size[0], size[1])
     op = next(i for i, o in enumerate(g.ops) if o.kind == 3)
     o = g.ops[op]
     tin, tout = g.tensors[o.in_], g.tensors[o.out]
     rng = np.random.default_rng(3)
-    x = rng.integers(0, 256, size=(16, tin.height, tin.width, tin.channels)).astype(np.float32)
+    x = rng.integers(0, 256, size=(nb, tin.height, tin.width, tin.channels)).astype(np.float32)
     x[..., 3] = 0
     bits = (x.view(np.uint32) >> 16).astype(np.uint16)        # small integers are exact in bf16
-    assert det.debug_op_kernels(16, op) == ["stem_persistent_kernel"] and det.debug_op_kernels(2, op) == ["stem_kernel"]
+    assert det.debug_op_kernels(nb, op) == ["stem_persistent_kernel"] and det.debug_op_kernels(2, op) == ["stem_kernel"]
     want = []
-    for i in range(0, 16, 2):
+    for i in range(0, nb, 2):
         det.debug_write(o.in_, bits[i:i + 2])
         det.debug_run(2, op, op)
         want.append(det.debug_read(o.out, 2, tout))
     want = np.concatenate(want)
-    for n in (16, 7):
+    for n in ((16, 7) if nb == 16 else (40, 37)):
         det.debug_write(o.in_, bits[:n])
         det.debug_write(o.out, np.full((n, tout.height, tout.width, tout.channels), 0x7fc0, np.uint16))
         det.debug_run(n, op, op)
