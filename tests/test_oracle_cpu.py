@@ -304,3 +304,13 @@ def test_device_expf_restatement_equals_the_host_libm(oracle):
     # and it is NOT the correctly rounded value everywhere: the reason the restatement exists
     cr = np.exp(dense.astype(np.float64)).astype(np.float32)
     assert 1e-6 < np.mean(cr != oracle.expf(dense)) < 1e-2
+
+
+def test_device_expf_restatement_equals_the_recorded_libm_vectors(oracle):
+    """The same restatement against committed vectors (tests/golden/expf_libm_glibc235.npz: 8 192 inputs and the outputs of glibc
+    2.35's expf on an x86-64 FMA host, written by tests/golden/make_expf_golden.py), so that it is pinned independently of the
+    libm of whatever host runs the tests."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expf_libm_glibc235.npz"))
+    got = oracle.expf(z["x"], restated=True)
+    assert np.array_equal(got.view(np.uint32), z["y"].view(np.uint32))

@@ -31,8 +31,9 @@ def _compare(oracle, det, heads, n, H, W, scales, conf=0.7, iou=0.45):
         assert np.array_equal(ggidx, ogidx), "kept index sequence differs (image %d)" % b
         assert det.last_total[b] == len(ogidx)
         assert np.array_equal(gdet[:, 4], odet[:, 4])
-        np.testing.assert_allclose(gdet[:, :4], odet[:, :4], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(glmk, olmk, rtol=0, atol=ATOL, equal_nan=True)
+        # bit-identical since round 4 (glibc's expf restated in the decode kernel); north_star's bar is 1e-4
+        assert np.array_equal(gdet[:, :4], odet[:, :4]), "box coordinates differ (image %d): max %g" % (b, np.nanmax(np.abs(gdet[:, :4] - odet[:, :4])))
+        assert np.array_equal(glmk, olmk, equal_nan=True), "landmarks differ (image %d)" % b
         exact += int(np.sum(gdet == odet)) + int(np.sum((glmk == olmk) | (np.isnan(glmk) & np.isnan(olmk))))
         total += gdet.size + glmk.size
     return exact, total
@@ -118,7 +119,7 @@ def test_all_anchors_pass_at_batch_64(rfd, oracle):
         odet, olmk, ogidx, ncand = ref[b % 4]
         assert ncand == 16800
         assert np.array_equal(got[b][2], ogidx)
-        np.testing.assert_allclose(got[b][0], odet, rtol=0, atol=ATOL)
+        assert np.array_equal(got[b][0], odet)          # all 16 800 decodes of the image, bit for bit
     d.close()
 
 
