@@ -776,7 +776,9 @@ extern "C" __attribute__((visibility("default"))) int rfd_debug_pair_prof(unsign
 // PX (round 4): 16-pixel groups per wave.  2 = a wave owns 32 pixels: every weight fragment read from LDS feeds TWO MFMAs (the
 // 16-pixel forms read one fragment per MFMA -- 8 MiB of LDS reads per 128 pixels, as many LDS cycles as the tile has MFMA cycles);
 // 4 waves x 32 pixels, one wave per SIMD with up to 512 registers, the deep ring.
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8, int PX = 1>
+// HALF1 (round 4): conv1 has 64 outputs (stage 1's units: 256 -> 64).  W1's 64 rows fill the first half of a slot (the other
+// half is never staged nor read), conv1 runs 4 row blocks per step instead of 8, t1's row pitch is 64.
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8, int PX = 1, bool HALF1 = false>
 __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const ConvParams p) // PX 1: 2 waves per SIMD (256 registers: two half workgroups fit a CU)
 {
 #ifdef RFD_PAIR_STAMPS
@@ -787,7 +789,9 @@ __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const
     constexpr bool SHORT = NW == 4 && PX == 1; // 2-slot ring, one step of lead, a drain per step
     static_assert((NW == 8 && PX == 1) || (NW == 4 && !RESIDENT && (PX == 1 || PX == 2)), "8 waves x 16 px, 4 x 16 (short ring) or 4 x 32");
     constexpr int BM = 16 * NW * PX, NT = 64 * NW, PQ = 16 / NW; // pixels per tile, threads, weight pieces per wave and step
-    constexpr int NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : (SHORT ? 2 : S + 1), N1 = 128 * N1B;
+    static_assert(!HALF1 || (N1B == 1 && NW == 8), "64-output conv1: one (half) row block, 8 waves");
+    constexpr int NKT = NK + NK2, S = NKT + 2 * N1B, WSLOTS = RESIDENT ? NCR * S : (SHORT ? 2 : S + 1), N1 = HALF1 ? 64 : 128 * N1B;
+    constexpr int RB1 = HALF1 ? 4 : 8; // 16-row blocks of a W1 slot-step that hold filter rows
     constexpr bool HAS_RES = NK2 == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Ws = reinterpret_cast<bf16_t *>(smem);                    // [WSLOTS][128*64]
@@ -838,7 +842,10 @@ __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const
         const uint32_t so = w3 ? (uint32_t)((((size_t)wi_nc * 128) * KT + (wi_s << 6)) * 2)
                                : w1_delta + (uint32_t)((((size_t)r1 * 128) * N + (wi_nc << 7) + (k1 << 6)) * 2);
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + NW * q) * 512);
+        for (int q = 0; q < PQ; ++q) {
+            if (HALF1 && !w3 && q * NW >= 8) continue; // slot rows 64 .. 127 of a 64-row W1: nothing there (NW = 8: pieces q >= 1)
+            blds16(rw, w3 ? woff[q] : woff1[q], (uint32_t)__builtin_amdgcn_readfirstlane(so), dst + (wave + NW * q) * 512);
+        }
         if (++wi_s == S) { wi_s = 0; if (++wi_nc == NC) wi_nc = 0; }
         wi_slot = wi_slot + 1 == WSLOTS ? 0 : wi_slot + 1;
     };
@@ -982,8 +989,13 @@ __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const
                     float a[8];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
-                        a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        if (HALF1) { // stage 1's kernels (conv_b2b_s1_*) round the product, then the sum: the same here, bit for bit
+                            a[2 * k] = fmaxf(bf16_bits_to_f32(rb[k] & 0xffffu) * sc[2 * k] + sh[2 * k], 0.f);
+                            a[2 * k + 1] = fmaxf(bf16_bits_to_f32(rb[k] >> 16) * sc[2 * k + 1] + sh[2 * k + 1], 0.f);
+                        } else {     // beyond stage 1 the pair's second conv is launch_conv's input affine: one fused multiply-add
+                            a[2 * k] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] & 0xffffu), sc[2 * k], sh[2 * k]), 0.f);
+                            a[2 * k + 1] = fmaxf(__builtin_fmaf(bf16_bits_to_f32(rb[k] >> 16), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        }
                     }
                     alo = pack_bf16x4(a[0], a[1], a[2], a[3]); ahi = pack_bf16x4(a[4], a[5], a[6], a[7]);
                 }
@@ -1008,7 +1020,7 @@ __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const
                     for (int kk = 0; kk < 2; ++kk) {
                         const int so = ((kk * 4 + fq) ^ (frow & 7)) << 3;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < RB1; ++i) {
                             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 1024 + so);
 #pragma unroll
                             for (int g = 0; g < PX; ++g)
@@ -1027,7 +1039,7 @@ __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const
 #pragma unroll
         for (int r1 = 0; r1 < N1B; ++r1)
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < RB1 / 2; ++h) {
                 const int n = r1 * 128 + h * 32 + fq * 8;
                 float b1[8];
                 lds_table_read8(Tab + 3 * N + n, b1);
@@ -1182,12 +1194,12 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_
     RFD_HIP(hipGetLastError());
     return RFD_OK;
 }
-template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
+template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, bool HALF1 = false> static int launch_pw_pair(const ConvParams &p, hipStream_t s)
 {
     // RFD_PAIR_HALF: which pairs run as half workgroups (bit mask: 1 stage 3's middle units <4,2>, 2 the 2 -> 3 boundary <2,2,true>,
     // 4 stage 2's first unit <2,1,false,4>, 8 stage 2's middle units); A/B knob, bit-identical either way
     static const int half_env = [] { const char *e = getenv("RFD_PAIR_HALF"); return e ? atoi(e) : 0; }();
-    if (NCR == 0) {
+    if (NCR == 0 && !HALF1) {
         const int bit = (NK == 4 && N1B == 2) ? 1 : (NK == 2 && N1B == 2) ? 2 : (NK == 2 && NK2 == 4) ? 4 : (NK == 2 && N1B == 1 && NK2 == 0) ? 8 : 0;
         if (half_env & bit) return launch_pw_pair_half<NK, N1B, ACT_OUT, NK2>(p, s);
         // RFD_PAIR_PX2: the same bit mask for the 32-pixel-per-wave form
@@ -1202,8 +1214,10 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0> static int la
     const size_t slots = NCR ? (size_t)NCR * (NK + NK2 + 2 * N1B) : (size_t)(NK + NK2 + 2 * N1B + 1);
     const size_t lds_need = slots * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
     if (NCR && p.Cout != NCR * 128) { set_error("pw_pair: resident form instantiated for %d output channels", NCR * 128); return RFD_ERR_INVALID_ARG; }
-    note_launch("pw_pair_kernel<%d, %d, %s, %d, %d>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
-    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2, NCR>>(grid, lds_need, s, p);
+    if (p.n1 != (HALF1 ? 64 : 128 * N1B)) { set_error("pw_pair: instantiated for n1 = %d, got %d", HALF1 ? 64 : 128 * N1B, p.n1); return RFD_ERR_INVALID_ARG; }
+    if (HALF1) note_launch("pw_pair_kernel<%d, %d, %s, %d, %d, 8, 1, true>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
+    else note_launch("pw_pair_kernel<%d, %d, %s, %d, %d>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
+    return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2, NCR, 8, 1, HALF1>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
 {
@@ -2793,6 +2807,21 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s)
     const int M = p.B * p.H * p.W;
     const size_t lds = (size_t)(128 * 64 + 256 * 64 + 4 * 128 * 64 + 4 * 64 * 64) * sizeof(bf16_t); // 144 KiB
     const int ntiles = ceil_div(M, 128);
+    // Round 4: the weight-resident barrier-free pair kernel (pw_pair_kernel<.., NCR = 2, HALF1>, the form that runs the stage
+    // 1 -> 2 boundary) takes stage 1's pairs too: W3 [256][64 or 128] + W1 [64][256] stay in LDS, every wave is an independent
+    // pipeline over its 16 pixels.  force_tile 16 forces it, 6 keeps the older persistent kernels below (RFD_S1_PAIR=0: always).
+    static const int s1_pair = [] { const char *e = getenv("RFD_S1_PAIR"); return e ? atoi(e) : 1; }();
+    const bool pair_ok = (const char *)p.w1 > (const char *)p.w3 && (size_t)((const char *)p.w1 - (const char *)p.w3) < (1u << 30) &&
+                         (p.Cin2 == 0 ? p.res != nullptr : (!p.res && p.bias3b)) && (size_t)M * 256 * 2 < 0xfffffff0ull;
+    if (pair_ok && (p.force_tile == 16 || (p.force_tile == 0 && s1_pair && ntiles >= 512))) {
+        ConvParams c;
+        memset(&c, 0, sizeof c);
+        c.x = p.x; c.w = p.w3; c.bias = p.bias3; c.x2 = p.x2; c.bias2 = p.bias3b; c.res = p.res;
+        c.scale2 = p.scale; c.shift2 = p.shift; c.y = p.raw; c.w1 = p.w1; c.bias1 = p.bias1; c.t1 = p.t1; c.n1 = 64;
+        c.B = p.B; c.H = c.Ho = c.H2 = p.H; c.W = c.Wo = c.W2 = p.W; c.Cin = p.Cin; c.Cin2 = p.Cin2; c.stride2 = 1; c.Cout = 256;
+        c.KH = c.KW = 1; c.stride = 1; c.ldx = p.Cin; c.ldy = 256; c.y_split = c.n_valid = 1 << 30; c.co_running = 1;
+        return p.Cin2 ? launch_pw_pair<1, 1, false, 1, 2, true>(c, s) : launch_pw_pair<1, 1, false, 0, 2, true>(c, s);
+    }
     // K1 = 64 and at least two tiles per CU: the persistent form (force_tile 7 opts out, 6 forces it whatever the size)
     if (p.Cin2 == 0 && p.force_tile != 7 && p.force_tile != 1 && p.force_tile != 2 && (ntiles >= 512 || p.force_tile == 6)) {
         const int per = ceil_div(ntiles, persistent_cus(1, true));

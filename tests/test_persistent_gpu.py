@@ -17,10 +17,13 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
     rng = np.random.default_rng(n)
     ops = []
     wide = set()
+    s1pair = set()
     for i, o in enumerate(g.ops):
         L = g.layers[o.layer]
         if o.kind == 6:   # stage-1 back-to-back kernel, with and without the fused shortcut: persistent forms (tile 6)
             ops.append(i)
+            if L.cin == 64 and g.layers[o.layer_b].cout == 64:   # ... and the weight-resident pair kernel (tile 16; round 4)
+                s1pair.add(i)
             continue
         if o.kind != 2:
             continue
@@ -37,7 +40,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
         if pw or c64 or pwg or pww:
             ops.append(i)
             wide.add(i) if pww else None
-    assert len(ops) >= 22 and len(wide) >= 5
+    assert len(ops) >= 22 and len(wide) >= 5 and len(s1pair) == 2
     checked = 0
     for i in ops:
         o = g.ops[i]
@@ -53,7 +56,7 @@ def test_persistent_kernels_equal_generic_kernels_bitwise(rfd, n):
         res = {}
         # 7: generic kernels only; 6: persistent kernels forced whatever the problem size (the first that accepts the layer);
         # 12: pw_wide_kernel forced (layers that pw_stream / pw_gemm would take first)
-        for tile in ((7, 6, 12) if i in wide else (7, 6)):
+        for tile in ((7, 6, 12) if i in wide else (7, 6, 16) if i in s1pair else (7, 6)):
             det.debug_set_conv_tile(tile)
             if o.out >= 0 and o.out == o.in_:   # SSH: the op writes a channel slice of its own input tensor
                 pass
