@@ -37,9 +37,39 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // cover), the L2-hot weight tile one step ahead; the one drain per step lands both (rounds 1-2 left the youngest
 // activation tile in flight behind a counted wait: no measurable difference, see wait_vmcnt).  128x128: 3*16 + 2*16 =
 // 80 KiB -> two workgroups fill the CU's 160 KiB exactly.
+#ifdef RFD_CLOCK_STAMPS // diagnostic build (tools/build_variant.sh clk -DRFD_CLOCK_STAMPS; tools/clock_stamps.py): the clock the chip
+// holds INSIDE each kernel class while the real pass runs -- sum of s_memtime deltas (shader cycles) over sum of s_memrealtime deltas
+// (100 MHz) of every workgroup, one pair of atomics per workgroup at its end (MI355X_MICROARCH.md, DVFS give-back item 6)
+__device__ unsigned long long g_clock_stamps[16][2];
+struct ClockStamp {
+    unsigned long long t0, r0;
+    int cls;
+    __device__ ClockStamp(int c) : cls(c) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ ~ClockStamp()
+    {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0, dr = __builtin_amdgcn_s_memrealtime() - r0;
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_clock_stamps[cls][0], dt);
+            atomicAdd(&g_clock_stamps[cls][1], dr);
+        }
+    }
+};
+#define RFD_CLOCK(cls) ClockStamp clock_stamp__(cls)
+extern "C" __attribute__((visibility("default"))) int rfd_debug_clock_stamps(unsigned long long *out, int reset)
+{
+    static unsigned long long host[32];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clock_stamps), sizeof host) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) out[i] = host[i];
+    if (reset) { memset(host, 0, sizeof host); if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_stamps), host, sizeof host) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define RFD_CLOCK(cls) do { } while (0)
+#endif
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSX, bool CHUNK_MAJOR = false>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv_igemm_kernel(const ConvParams p)
 {
+    RFD_CLOCK(0);
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -325,6 +355,7 @@ __device__ __forceinline__ void lds_table_read8x3(const float *t0, const float *
 template <int NK, bool HAS_Y, bool HAS_Y2>
 __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 {
+    RFD_CLOCK(1);
     constexpr int BM = 128, WSLOTS = NK + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);   // [NK][BM*64]
@@ -513,6 +544,7 @@ __global__ void __launch_bounds__(512) pw_stream_kernel(const ConvParams p)
 template <int NK, bool ACT_OUT>
 __global__ void __launch_bounds__(512) pw_b2b_kernel(const ConvParams p)
 {
+    RFD_CLOCK(2);
     constexpr int BM = 128, S = NK + 2, WSLOTS = S + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);   // [NK][BM*64]
@@ -781,6 +813,7 @@ extern "C" __attribute__((visibility("default"))) int rfd_debug_pair_prof(unsign
 template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, int NW = 8, int PX = 1, bool HALF1 = false>
 __global__ void __launch_bounds__(NW * 64, PX == 2 ? 1 : 2) pw_pair_kernel(const ConvParams p) // PX 1: 2 waves per SIMD (256 registers: two half workgroups fit a CU)
 {
+    RFD_CLOCK(3);
 #ifdef RFD_PAIR_STAMPS
     unsigned long long prof[10] = {}, tlast = __builtin_readcyclecounter();
     const unsigned long long tstart = tlast;
@@ -1244,6 +1277,7 @@ template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_
 template <int BN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const ConvParams p)
 {
+    RFD_CLOCK(4);
     constexpr int BM = 128, XE = 160; // extended tile rows (20 pieces)
     constexpr int NW = WAVES_M * WAVES_N;
     static_assert(NW == 4, "piece distribution assumes 4 waves");
@@ -1394,6 +1428,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
 constexpr int kC64T = 16, kC64H = kC64T + 2, kC64HP = 41 /* pieces of 8 rows */;
 __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, int tiles_x, int tiles_y)
 {
+    RFD_CLOCK(5);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Wt = reinterpret_cast<bf16_t *>(smem);       // [9][64][64]
     bf16_t *Xh = Wt + 9 * 64 * 64;                        // [2][kC64HP*8][64]
@@ -1556,6 +1591,7 @@ static int launch_conv3x3_c64(const ConvParams &p, hipStream_t s)
 template <int TC, int TR, int TN>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int n_items)
 {
+    RFD_CLOCK(6);
     constexpr int HW2 = TC + 2, HPX = (TR + 2) * HW2, HP = (HPX + 7) / 8; // halo pixels, 8-pixel DMA pieces
     constexpr int HQ = (HP + 3) / 4;                                       // pieces per halo wave
     constexpr int HEL = HP * 512;                                          // elements per halo buffer
@@ -1832,6 +1868,7 @@ static int launch_conv3x3_kx(const ConvParams &p, hipStream_t s)
 template <bool HAS_AFF, bool WIDE>
 __global__ void __launch_bounds__(512) pw_gemm_kernel(const ConvParams p, int tiles_m, int n_items)
 {
+    RFD_CLOCK(7);
     constexpr int BM = WIDE ? 128 : 256, NWG = WIDE ? 256 : 128, XEL = BM * 64, WEL = NWG * 64;
     constexpr int WMW = BM / 64; // waves along the pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2099,8 +2136,12 @@ static int launch_pw_gemm(const ConvParams &p, hipStream_t s)
 // segment (the 1x1 stride-2 shortcut conv over x2: a per-lane pixel gather), residual, raw + activated outputs -- the
 // generic kernel's epilogue arithmetic in the same order, and the same K order: bit-identical results.
 // ------------------------------------------------------------------------------------------------
+#ifndef RFD_WIDE_EXP
+#define RFD_WIDE_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage): 1 no operand DMA, 2 no DMA + no step barrier, 3 DMA issued but never waited for
+#endif
 __global__ void __launch_bounds__(512) pw_wide_kernel(const ConvParams p, int n_items)
 {
+    RFD_CLOCK(8);
     constexpr int BM = 256, NWG = 256, XEL = BM * 64, WEL = NWG * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);        // [2][XEL]
@@ -2188,11 +2229,17 @@ __global__ void __launch_bounds__(512) pw_wide_kernel(const ConvParams p, int n_
     while (true) {
         int nit = item, nk = k + 1;
         if (nk == KC) { nk = 0; nit = item + grid; }
+#if RFD_WIDE_EXP != 3
         wait_vmcnt<0>();
+#endif
+#if RFD_WIDE_EXP != 2
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         // the next item's second-segment pixels: needed from its step KC1 on, so recomputed one step into the item
         if (p.Cin2 && k == 0 && item != item0) item_x2(item);
+#if RFD_WIDE_EXP == 0 || RFD_WIDE_EXP == 3
         if (nit < n_items) issue(sl ^ 1, nit, nk);
+#endif
         const bf16_t *xb = Xs + sl * XEL, *wb = Ws + sl * WEL;
         bf16x8 af[2][4], bfr[2][4];
         auto load_group = [&](int g) { // group g -> (kk = g >> 1, A fragments 4 (g & 1) ..); B fragments with the first of a kk
@@ -2318,6 +2365,7 @@ static int launch_pw_wide(const ConvParams &p, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
 {
+    RFD_CLOCK(9);
     constexpr int BM = 128, N1 = 256, N2 = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [128][64]
@@ -2494,6 +2542,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_kernel(const B2BParams p)
 // of a tile covers DMAs and stores issued at least a phase earlier.  Same arithmetic in the same order: bit-identical.
 __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_kernel(const B2BParams p, int ntiles)
 {
+    RFD_CLOCK(10);
     constexpr int BM = 128, N1 = 256, N2 = 64, K1 = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [128][64]
@@ -2664,6 +2713,7 @@ __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_kernel(const B2BPa
 // 4 x 2 waves x (16 pixels x 32 channels).  Same K order and arithmetic as conv_b2b_s1_kernel: bit-identical.
 __global__ void __launch_bounds__(512) conv_b2b_s1_persistent_k128_kernel(const B2BParams p, int ntiles)
 {
+    RFD_CLOCK(11);
     constexpr int BM = 64, N1 = 256, N2 = 64, K1 = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem);  // [2 k-tiles][64][64]
@@ -3287,6 +3337,7 @@ __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__re
                                                               const float *__restrict__ shift, bf16_t *__restrict__ y, int H,
                                                               int W, int tiles_w, int tiles_h, int ntiles, int per)
 {
+    RFD_CLOCK(12);
     __shared__ __attribute__((aligned(16))) uint2 in_tile[kStemIR * kStemIP];
     __shared__ __attribute__((aligned(16))) bf16_t conv_tile[kStemCR * kStemCC * kStemCP];
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
