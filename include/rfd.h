@@ -344,8 +344,9 @@ RFD_API int rfd_get_op_profile(rfd_ctx *ctx, float *ms, int cap);
  *      op list [first_op, last_op] (last_op < 0: to the end), so every op can be checked in isolation. */
 RFD_API int rfd_debug_tensor_io(rfd_ctx *ctx, int tensor_id, int n, void *host, int write);
 RFD_API int rfd_debug_run_ops(rfd_ctx *ctx, int n, int first_op, int last_op);
-/* force the conv tile configuration: 0 = heuristic, 1 = 128-row tiles, 2 = 256x128 tiles where legal, 17 = the
- * wave-specialised ring form wherever the layer shape allows (the full list: launch_conv in csrc/kernels_conv.hip) */
+/* force the conv tile configuration: 0 = heuristic, 1 = 128-row four-wave tiles, 2 = 256x128 tiles where legal, 16 = the
+ * weight-resident pair kernel for stage 1's pairs, 17 = the wave-specialised ring form wherever the layer shape allows, 18 = the
+ * eight-wave 128x128 generic tile, 19 = the four-wave merged-kx 3x3 kernel (the full list: launch_conv in csrc/kernels_conv.hip) */
 RFD_API int rfd_debug_set_conv_tile(rfd_ctx *ctx, int tile);
 /* which kernel(s) op `op` of the network would be run by at `n` images per chain (co_running != 0: as one of the two chains of a
  * split pass) -- the names rocprofv3 reports without the rfd:: prefix, " + "-separated when an op takes two launches.  Nothing is

@@ -1275,15 +1275,15 @@ template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_
 // LDS: 2 x 20 KiB activation slots + 2 weight slots: 72 KiB at BN = 128 -> two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 template <int BN, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const ConvParams p)
+__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64, 2) conv3x3_kx_kernel(const ConvParams p) // two waves per SIMD: <= 256 registers, so that two 4-wave workgroups share a CU (a guard in stage_x once cost 20 registers and the co-residency: 67 -> 108 us)
 {
     RFD_CLOCK(4);
     constexpr int BM = 128, XE = 160; // extended tile rows (20 pieces)
     constexpr int NW = WAVES_M * WAVES_N;
-    static_assert(NW == 4, "piece distribution assumes 4 waves");
+    static_assert(NW == 4 || NW == 8, "4 waves (64 x 64 wave tiles) or 8 (32 x 64: two waves per SIMD from ONE workgroup, for grids that give a CU a single workgroup)");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int XPE = XE / 8 / NW, WP = (BN / 8 + NW - 1) / NW; // 5 activation pieces per wave and (ky, chunk)
+    constexpr int XPE = (XE / 8 + NW - 1) / NW, WP = (BN / 8 + NW - 1) / NW; // 5 (8 waves: 3, the last for waves 0-3 only) activation pieces per wave and (ky, chunk)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(smem); // [2][XE*64]
@@ -1333,6 +1333,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) conv3x3_kx_kernel(const
         const uint32_t rowoff = (uint32_t)(ky * p.W * p.ldx * 2);
 #pragma unroll
         for (int q = 0; q < XPE; ++q) {
+            if (XPE * NW > XE / 8 && wave + NW * q >= XE / 8) continue; // 8 waves: the last round is for waves 0-3 only (wave-uniform)
             const bool ok = (unsigned)(y0[q] + ky) < (unsigned)p.H;
             blds16(rx, ok ? xoff[q] + rowoff : kOob, (uint32_t)(kc << 7), Xs + slot * XE * 64 + (wave + NW * q) * 512);
         }
@@ -3002,6 +3003,13 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         q.k_chunk_major = 1;
         return launch_conv(q, s);
     }
+    // force_tile 18: the generic 128 x 128 tile with EIGHT waves (32 x 64 wave tiles, two waves per SIMD from one workgroup): for
+    // the small-M layers whose grid gives a CU a single workgroup (A/B; bit-identical, same K order)
+    if (p.force_tile == 18 && p.Cout % 128 == 0 && !p.in_scale) return launch_conv_cfg<128, 128, 4, 2, 3>(p, s);
+    // force_tile 19: the merged-kx 3x3 kernel in its older four-wave form (64 x 64 wave tiles)
+    if (p.force_tile == 19 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H && p.Wo == p.W &&
+        p.W >= 3 && p.Cout % 128 == 0)
+        return launch_conv3x3_kx<128, 2, 2>(p, s);
     // wave-specialised loader / consumer ring (kernels_ring.hip): force_tile 17 = wherever the shape allows (tests, A/B)
     if (p.force_tile == 17 && conv_ring_supports(p, nullptr)) return launch_conv_ring(p, s);
     {   // The ring runs the small-M, long-K layers it measured faster on, in its generic form: stage-4 conv1 (2048 -> 512: 27.3 vs
@@ -3069,7 +3077,13 @@ int launch_conv(const ConvParams &p, hipStream_t s)
     }
     const bool kx_ok = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin2 == 0 && !p.in_scale && p.Ho == p.H &&
                        p.Wo == p.W && p.W >= 3 && p.force_tile != 1 && p.force_tile != 2;
-    if (kx_ok && p.Cout % 128 == 0) return launch_conv3x3_kx<128, 2, 2>(p, s);
+    // Eight waves (32 x 64 wave tiles) since round 4: the layers that come here have small grids (stage-4 conv2: 200 tiles on 256
+    // CUs), so a CU mostly holds ONE workgroup, and with four waves that is one wave per SIMD -- nothing covers its barrier, drain
+    // and fragment-read latencies (1 725 cycles per 32-MFMA step).  Two waves per SIMD from the same workgroup: 53.8 -> 46.1 us
+    // (stage-4 conv2, 16 images), 73 -> 65 us at 32 images where two four-wave workgroups already shared a CU, 30.5 -> 27.4 us
+    // (SSH 80 x 80 context conv); same K order, bit-identical (force_tile 19: the four-wave form).
+    static const int tile_waves = [] { const char *e = getenv("RFD_TILE_WAVES"); return e ? atoi(e) : 8; }(); // 4: the older forms (A/B)
+    if (kx_ok && p.Cout % 128 == 0) return tile_waves == 4 ? launch_conv3x3_kx<128, 2, 2>(p, s) : launch_conv3x3_kx<128, 4, 2>(p, s);
     // (with BN = 64 the merged-kx kernel measured 7 % slower than the generic 128x64 tile at 3 workgroups / CU)
     // Per-layer tile choice for a chain that has the GPU to itself (unsplit passes, B < 16; tools/tile_sweep.py): the
     // 128x64 tile (3 workgroups per CU, twice the grid) wins by 5-28 % where the 128x128 grid cannot give every CU a
@@ -3088,6 +3102,9 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         if (p.force_tile == 2) return launch_conv_cfg<256, 128, 4, 2, 3>(p, s);
         // the 80 KiB ring leaves no room for the input-affine table next to a second workgroup
         if (p.force_tile == 1 || p.in_scale) return launch_conv_cfg<128, 128, 2, 2, 2>(p, s);
+        // eight waves on the 128 x 128 tile (round 4; as in the merged-kx kernel above): 46.5 vs 49.5 us and 39.2 vs 41.0 us on the
+        // stride-2 3x3 layers, 24.8 vs 26.2 us on the 1024 -> 256 lateral; the K = 2048 lateral ties (26.5 vs 26.0) and keeps four
+        if (tile_waves != 4 && !(p.KH == 1 && p.Cin + p.Cin2 >= 2048)) return launch_conv_cfg<128, 128, 4, 2, 3>(p, s);
         return launch_conv_cfg<128, 128, 2, 2, 3>(p, s);
     }
     if (p.Cout % 192 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 192, 2, 2, 2>(p, s); // fused SSH pair

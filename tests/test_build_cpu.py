@@ -169,7 +169,7 @@ def test_every_persistent_kernel_requests_the_whole_cu(disasm, tmp_path):
     for block in txt.split("- .agpr_count:")[1:]:
         nm = re.search(r"\.name:\s+(\S+)", block).group(1)
         wg[nm] = (int(re.search(r"\.max_flat_workgroup_size:\s+(\d+)", block).group(1)), int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", block).group(1)))
-    one_tile_per_workgroup = ("conv_b2b_s1_kernel", "conv_igemm_kernel")   # 8-wave, LDS-DMA, NOT persistent: sized to co-reside
+    one_tile_per_workgroup = ("conv_b2b_s1_kernel", "conv_igemm_kernel", "conv3x3_kx_kernel")   # 8-wave, LDS-DMA, NOT persistent: sized to co-reside
     seen = set()
     for name, ins in disasm["kernels_conv"].items():
         if wg[name][0] != 512 or not isa_check.uses_lds_dma(ins):

@@ -73,6 +73,59 @@ def test_ring_kernels_equal_barrier_kernels_bitwise(rfd, n):
     det.close()
 
 
+@pytest.mark.parametrize("n", [16, 3])
+def test_eight_wave_tiles_equal_four_wave_tiles_bitwise(rfd, n):
+    """Round 4: the one-tile-per-workgroup kernels run the 128 x 128 tile with EIGHT waves (32 x 64 wave tiles: two waves per SIMD
+    from one workgroup) where the grid gives a CU a single workgroup -- conv3x3_kx_kernel<128, 4, 2> and
+    conv_igemm_kernel<128, 128, 4, 2, 3>, what force_tile 7 (and 0 at small sizes) now selects.  Same K order, same MFMA sequence per
+    output: bit-identical to the four-wave forms (force_tile 19: the four-wave merged-kx kernel; force_tile 1: the four-wave
+    generic tile for every conv)."""
+    det = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=16, max_det=16)
+    det.init_synthetic_weights(1234)
+    g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
+    rng = np.random.default_rng(200 + n)
+    ops = _ring_ops(g)
+    names = set()
+    for i in ops:
+        o = g.ops[i]
+        L = g.layers[o.layer]
+        det.debug_set_conv_tile(GENERIC)
+        names.update(det.debug_op_kernels(n, i))
+        for t in (o.in_, o.res, o.in2):
+            if t < 0:
+                continue
+            td = g.tensors[t]
+            x = rng.normal(0, 1, size=(n, td.height, td.width, td.channels)).astype(np.float32)
+            if t == o.in_ and o.in_affine < 0:
+                x = np.maximum(x, 0)
+            det.debug_write(t, (x.view(np.uint32) >> 16).astype(np.uint16))
+        outs = [t for t in (o.out, o.out2) if t >= 0]
+        res = {}
+        # (a 3x3 stride-1 layer that the halo kernel does not take -- W = 20 -- accumulates chunk-major in the merged-kx kernel and
+        #  tap-major in the generic one: tile 1 is not its four-wave form, tile 19 is)
+        kx_layer = L.kh == 3 and L.stride == 1
+        tiles = (GENERIC, 19) if kx_layer else (GENERIC, 1)
+        for tile in tiles:
+            det.debug_set_conv_tile(tile)
+            for t in outs:
+                if t != o.in_:
+                    td = g.tensors[t]
+                    det.debug_write(t, np.full((n, td.height, td.width, td.channels), 0x7fc0, np.uint16))  # NaN poison
+            det.debug_run(n, i, i)
+            res[tile] = [det.debug_read(t, n, g.tensors[t]) for t in outs]
+        for tile in tiles[1:]:
+            for t, a, b in zip(outs, res[tile], res[GENERIC]):
+                if t == o.in_:
+                    a, b = a[..., o.y_coff:o.y_coff + L.cout], b[..., o.y_coff:o.y_coff + L.cout]
+                bad = int((a != b).sum())
+                assert bad == 0, "op %d (%s k%d %d->%d) tensor %d: tile %d differs from the eight-wave form in %d / %d elements at n = %d" % (
+                    i, L.name.decode(), L.kh, L.cin, L.cout, t, tile, bad, a.size, n)
+    det.debug_set_conv_tile(0)
+    det.close()
+    assert any(k.startswith("conv3x3_kx_kernel<128, 4, 2>") for k in names), names
+    assert any(k.startswith("conv_igemm_kernel<128, 128, 4, 2, 3") for k in names), names
+
+
 def test_ring_give_up_word_is_an_error_not_wrong_results(rfd):
     """A ring wave that stops waiting marks the context's device fault word (the one the chunked NMS reports into); the host
     reads it back behind the pass and every entry point returns an error instead of tensors nobody can trust
