@@ -3107,7 +3107,9 @@ int launch_conv(const ConvParams &p, hipStream_t s)
         if (tile_waves != 4 && !(p.KH == 1 && p.Cin + p.Cin2 >= 2048)) return launch_conv_cfg<128, 128, 4, 2, 3>(p, s);
         return launch_conv_cfg<128, 128, 2, 2, 3>(p, s);
     }
-    if (p.Cout % 192 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 192, 2, 2, 2>(p, s); // fused SSH pair
+    // fused SSH pair (conv1 + ctx1 along N): eight waves (32 x 96 wave tiles) since round 4 -- these layers have at most 50 tiles
+    // below the halo kernel's threshold, one workgroup per CU, and the four-wave form needs 284 registers (one wave per SIMD)
+    if (p.Cout % 192 == 0 && p.Cout % 128 != 0) return (tile_waves == 4 || p.force_tile == 1 || p.force_tile == 19) ? launch_conv_cfg<128, 192, 2, 2, 2>(p, s) : launch_conv_cfg<128, 192, 4, 2, 2>(p, s);
     // 128x64: the 2-slot ring keeps 3 workgroups per CU, which measured faster than a deeper ring at 2
     if (p.Cout % 64 == 0) {
         if (p.force_tile == 3) return launch_conv_cfg<256, 64, 4, 1, 2>(p, s); // 64x64 wave tiles, 2 workgroups / CU

@@ -24,6 +24,13 @@ def _ring_ops(g):
     return ops
 
 
+def _tile_ops(g):
+    """... and the fused SSH pairs (Cout = 192: the 128 x 192 tile, which the ring does not take)"""
+    extra = [i for i, o in enumerate(g.ops) if o.kind == 2 and o.layer_b < 0 and o.layer_n2 >= 0
+             and g.layers[o.layer].cout + g.layers[o.layer_n2].cout == 192]
+    return sorted(set(_ring_ops(g)) | set(extra))
+
+
 @pytest.mark.parametrize("n", [16, 5, 1])
 def test_ring_kernels_equal_barrier_kernels_bitwise(rfd, n):
     det = rfd.RetinaFaceDetection(image_size=(640, 640), max_batch_size=16, max_det=16)
@@ -84,7 +91,7 @@ def test_eight_wave_tiles_equal_four_wave_tiles_bitwise(rfd, n):
     det.init_synthetic_weights(1234)
     g = rfd.Graph(rfd.BACKBONE_R50, 640, 640)
     rng = np.random.default_rng(200 + n)
-    ops = _ring_ops(g)
+    ops = _tile_ops(g)
     names = set()
     for i in ops:
         o = g.ops[i]
@@ -124,6 +131,7 @@ def test_eight_wave_tiles_equal_four_wave_tiles_bitwise(rfd, n):
     det.close()
     assert any(k.startswith("conv3x3_kx_kernel<128, 4, 2>") for k in names), names
     assert any(k.startswith("conv_igemm_kernel<128, 128, 4, 2, 3") for k in names), names
+    assert n > 8 or any(k.startswith("conv_igemm_kernel<128, 192, 4, 2, 2") for k in names), names   # (n = 16: the halo kernel takes them)
 
 
 def test_ring_give_up_word_is_an_error_not_wrong_results(rfd):
