@@ -1199,7 +1199,7 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_
     // each workgroup asks for HALF the CU's LDS, so that exactly two co-reside (and nothing else beside them)
     constexpr size_t kHalfLds = 80 * 1024;
     if (lds_need > kHalfLds) { set_error("pw_pair (half workgroups): %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
-    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4>", NK, N1B, ACT_OUT ? "true" : "false", NK2);
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4, 1, false>", NK, N1B, ACT_OUT ? "true" : "false", NK2); // the name rocprofv3 reports: every template argument
     if (launch_note().dry) return RFD_OK;
     auto kern = pw_pair_kernel<NK, N1B, ACT_OUT, NK2, 0, 4>;
     static DynLdsOnce once;
@@ -1218,7 +1218,7 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0> static int launch_pw_pair_
     const int grid = ceil_div(tiles_m, per);
     const size_t lds_need = (size_t)(NK + NK2 + 2 * N1B + 1) * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
     if (lds_need > kPersistentLds) { set_error("pw_pair (32 px per wave): %zu bytes of LDS needed", lds_need); return RFD_ERR_CAPACITY; }
-    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4, 2>", NK, N1B, ACT_OUT ? "true" : "false", NK2);
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, 0, 4, 2, false>", NK, N1B, ACT_OUT ? "true" : "false", NK2);
     if (launch_note().dry) return RFD_OK;
     auto kern = pw_pair_kernel<NK, N1B, ACT_OUT, NK2, 0, 4, 2>;
     static DynLdsOnce once;
@@ -1248,8 +1248,7 @@ template <int NK, int N1B, bool ACT_OUT, int NK2 = 0, int NCR = 0, bool HALF1 = 
     const size_t lds_need = slots * 128 * 64 * sizeof(bf16_t) + (size_t)(3 * p.Cout + 128 * N1B) * sizeof(float);
     if (NCR && p.Cout != NCR * 128) { set_error("pw_pair: resident form instantiated for %d output channels", NCR * 128); return RFD_ERR_INVALID_ARG; }
     if (p.n1 != (HALF1 ? 64 : 128 * N1B)) { set_error("pw_pair: instantiated for n1 = %d, got %d", HALF1 ? 64 : 128 * N1B, p.n1); return RFD_ERR_INVALID_ARG; }
-    if (HALF1) note_launch("pw_pair_kernel<%d, %d, %s, %d, %d, 8, 1, true>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
-    else note_launch("pw_pair_kernel<%d, %d, %s, %d, %d>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR);
+    note_launch("pw_pair_kernel<%d, %d, %s, %d, %d, 8, 1, %s>", NK, N1B, ACT_OUT ? "true" : "false", NK2, NCR, HALF1 ? "true" : "false");
     return launch_persistent<pw_pair_kernel<NK, N1B, ACT_OUT, NK2, NCR, 8, 1, HALF1>>(grid, lds_need, s, p);
 }
 template <int NK> static int launch_pw_stream_nk(const ConvParams &p, hipStream_t s)
