@@ -300,8 +300,10 @@ RFD_API int rfd_collect_batch(rfd_ctx *ctx, rfd_dets *out, int *n_out);
 /* ---- FaceAlignment: FaceAlignment::call, src/pipeline/module/face_alignment.rs:27-141 --
  *      the step after selection in FacePipeline::extract (pipeline.rs:210-216).  For each frame the selected face is
  *      mapped onto the out_w x out_h template: 4-DOF similarity from its five key points to `standard_landmarks`
- *      (replaces estimate_affine_partial_2d(LMEDS) :48-60 by the closed-form least-squares similarity it refines to
- *      -- a documented divergence) + cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) :112-120 restated in integer
+ *      as estimate_affine_partial_2d(LMEDS, 3.0, 2000, 0.99, 10) :48-60 computes it -- OpenCV's LMedS restated: 13
+ *      two-point samples of the re-seeded cv::RNG, least median, inlier rule, least squares over the inliers (the
+ *      fixed point of its Levenberg-Marquardt refinement; parity against a running OpenCV unpinned)
+ *      + cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) :112-120 restated in integer
  *      arithmetic; degenerate key points take the reference's crop + resize branch :62-110.
  *      Defaults = FaceAlignmentConfig::new (config.rs:44-56): 112 x 112 and the ArcFace template.
  *      status[i]: 0 aligned, 1 crop + resize fallback, -1 no key points (the reference's call returns Err),

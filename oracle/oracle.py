@@ -215,13 +215,43 @@ STANDARD_LANDMARKS = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252,
                                [70.7299, 92.2041]], np.float32)
 
 
-def estimate_similarity(src, dst):
-    """closed-form 4-DOF least-squares similarity src -> dst; returns the 2x3 f64 matrix or None (degenerate)."""
+def estimate_similarity(src, dst, all_points=False, return_inliers=False):
+    """cv::estimateAffinePartial2D(src -> dst, LMEDS, 3.0, 2000, 0.99, 10) restated (face_alignment.rs:48-60): 13 fixed two-point
+    samples, least median, inlier rule, least squares over the inliers.  all_points: the closed form over every point (rounds 1-3).
+    Returns the 2x3 f64 matrix or None (no model: the reference's empty-matrix branch)."""
     s = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
     d = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
     M = np.zeros(6, np.float64)
-    ok = lib().rfd_oracle_estimate_similarity(s, d, s.shape[0], M)
+    L = lib()
+    if all_points:
+        L.rfd_oracle_estimate_similarity_all_points.argtypes = L.rfd_oracle_estimate_similarity.argtypes
+        L.rfd_oracle_estimate_similarity_all_points.restype = C.c_int
+        ok = L.rfd_oracle_estimate_similarity_all_points(s, d, s.shape[0], M)
+        return M.reshape(2, 3) if ok else None
+    inl = np.zeros(s.shape[0], np.uint8)
+    L.rfd_oracle_estimate_similarity_lmeds.argtypes = list(L.rfd_oracle_estimate_similarity.argtypes) + [np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+    L.rfd_oracle_estimate_similarity_lmeds.restype = C.c_int
+    ok = L.rfd_oracle_estimate_similarity_lmeds(s, d, s.shape[0], M, inl)
+    if return_inliers:
+        return (M.reshape(2, 3) if ok else None), inl.astype(bool)
     return M.reshape(2, 3) if ok else None
+
+
+def lmeds_samples(n):
+    """the two-point index pairs OpenCV's LMeDS draws for n points (cv::RNG re-seeded with (uint64)-1 on every call)"""
+    L = lib()
+    L.rfd_oracle_lmeds_samples.argtypes = [C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int]
+    L.rfd_oracle_lmeds_samples.restype = C.c_int
+    p = np.zeros(128, np.int32)
+    k = L.rfd_oracle_lmeds_samples(n, p, 64)
+    return p[:2 * k].reshape(-1, 2)
+
+
+def cv_ransac_num_iters(p, ep, model_points, max_iters):
+    L = lib()
+    L.rfd_oracle_cv_ransac_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    L.rfd_oracle_cv_ransac_num_iters.restype = C.c_int
+    return L.rfd_oracle_cv_ransac_num_iters(p, ep, model_points, max_iters)
 
 
 def warp_affine(src, M, out_h, out_w):

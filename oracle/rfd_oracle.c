@@ -16,6 +16,7 @@
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  * Arithmetic is IEEE f32 in the written operation order: compile with -ffp-contract=off.
  */
+#include <float.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -588,38 +589,180 @@ RFD_API int rfd_oracle_face_selection(const float *boxes, const float *kps, int 
  *
  * Third-party arithmetic, "parity unpinned" (no OpenCV in this image, the reference's test is commented out,
  * face_alignment.rs:148-240):
- *  - estimate_affine_partial_2d(landmarks -> template, LMEDS, 3.0, 2000, 0.99, 10) (:48-60) is OpenCV calib3d:
- *    random 2-point samples, least-median selection, then 10 Levenberg-Marquardt iterations on the inliers.
- *    The refined model minimises the squared reprojection error of a 4-DOF similarity [a -b tx; b a ty], a
- *    LINEAR least-squares problem; with all five landmarks inliers its unique minimum is the closed form below.
- *    DOCUMENTED DIVERGENCE: the closed form over all five points replaces sampling + refinement (no outlier
- *    rejection); a degenerate input (all landmarks coincide) takes the reference's empty-matrix branch (:62).
+ *  - estimate_affine_partial_2d(landmarks -> template, LMEDS, 3.0, 2000, 0.99, 10) (:48-60) is OpenCV calib3d
+ *    (modules/calib3d/src/ptsetreg.cpp, OpenCV 4.x; the crate pins opencv 0.92 -> system OpenCV 4, unpinned).
+ *    Round 4 restates its published algorithm instead of replacing it by an all-points least squares (round-3 review:
+ *    with one bad landmark LMedS drops it and the closed form does not -- and even on clean points the inlier rule
+ *    below often keeps 3 or 4 of the 5):
+ *      LMeDSPointSetRegistrator::run -- niters = RANSACUpdateNumIters(0.99, outlier ratio 0.45, 2 model points, 2000)
+ *        = 13; cv::RNG seeded with (uint64)-1 on EVERY call, so the 13 two-point samples are the same index pairs for
+ *        every face (getSubset: uniform(0, count) draws, a repeated index is redrawn; two points are never "collinear");
+ *        per sample the exact similarity through the two pairs (AffinePartial2DEstimatorCallback::runKernel, f64),
+ *        squared reprojection errors of all points in f32 (computeError), their median; the sample with the smallest
+ *        median wins (strict <, so NaN models of coincident points never do); sigma = 2.5 * 1.4826 * (1 + 5 / (count - 2))
+ *        * sqrt(min median), at least 0.001; inliers: error <= (float)(sigma^2); fewer than 2 inliers -> empty matrix.
+ *      refinement (count > 2, refineIters = 10): cv::LMSolver on the inliers minimises the squared reprojection error of
+ *        [a -b tx; b a ty] -- a LINEAR least-squares problem: Levenberg-Marquardt drops its damping after the first
+ *        accepted step (lambda 1 -> 0.5 < 0.75 -> 0) and the next, undamped Gauss-Newton step lands on the unique minimum,
+ *        the closed form below over the inliers.  DOCUMENTED DIVERGENCE (~1e-12): the closed form stands in for those
+ *        iterations.
+ *    Written from the published sources as known, not checked against a running OpenCV: parity unpinned.
  *  - warp_affine(INTER_LINEAR, BORDER_CONSTANT, 0) (:112-120) restates cv::warpAffine (imgwarp.cpp): the 2x3
  *    matrix is inverted in f64, coordinates are 10-bit fixed point (AB_BITS) reduced to 5 fractional bits
  *    (INTER_BITS), bilinear weights are the 15-bit table products, out-of-image taps read 0, result
  *    (sum + 2^14) >> 15.
  * ------------------------------------------------------------------------------------------ */
-RFD_API int rfd_oracle_estimate_similarity(const float *src, const float *dst, int n, double M[6])
+/* closed-form least-squares similarity over the points with use[i] != 0 (use == NULL: all) */
+static int similarity_ls(const float *src, const float *dst, int n, const unsigned char *use, double M[6])
 {
     double msx = 0, msy = 0, mdx = 0, mdy = 0;
+    int m = 0;
     for (int i = 0; i < n; ++i) {
+        if (use && !use[i]) continue;
         msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
         mdx += (double)dst[2 * i]; mdy += (double)dst[2 * i + 1];
+        ++m;
     }
-    msx /= n; msy /= n; mdx /= n; mdy /= n;
+    if (m == 0) return 0;
+    msx /= m; msy /= m; mdx /= m; mdy /= m;
     double sxx = 0, sa = 0, sb = 0;
     for (int i = 0; i < n; ++i) {
+        if (use && !use[i]) continue;
         const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
         const double xd = (double)dst[2 * i] - mdx, yd = (double)dst[2 * i + 1] - mdy;
         sxx += xs * xs + ys * ys;
         sa += xs * xd + ys * yd;
         sb += xs * yd - ys * xd;
     }
-    if (!(sxx > 0.0)) return 0; /* degenerate: the reference's `transformation_matrix.empty()` branch */
+    if (!(sxx > 0.0)) return 0;
     const double a = sa / sxx, b = sb / sxx;
     M[0] = a; M[1] = -b; M[2] = mdx - (a * msx - b * msy);
     M[3] = b; M[4] = a;  M[5] = mdy - (b * msx + a * msy);
     return 1;
+}
+
+/* cv::RNG (core/operations.hpp): multiply-with-carry, CV_RNG_COEFF 4164903690 */
+static unsigned cv_rng_next(uint64_t *state)
+{
+    *state = (uint64_t)(unsigned)*state * 4164903690u + (unsigned)(*state >> 32);
+    return (unsigned)*state;
+}
+static int cv_rng_uniform(uint64_t *state, int a, int b) { return a == b ? a : (int)(cv_rng_next(state) % (unsigned)(b - a)) + a; }
+
+/* RANSACUpdateNumIters (ptsetreg.cpp) */
+RFD_API int rfd_oracle_cv_ransac_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : (p > 1 ? 1 : p);
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+/* AffinePartial2DEstimatorCallback::runKernel: the similarity through two point pairs */
+static void similarity_2pt(const float *src, const float *dst, int i0, int i1, double M[6])
+{
+    const double x1 = src[2 * i0], y1 = src[2 * i0 + 1], x2 = src[2 * i1], y2 = src[2 * i1 + 1];
+    const double X1 = dst[2 * i0], Y1 = dst[2 * i0 + 1], X2 = dst[2 * i1], Y2 = dst[2 * i1 + 1];
+    const double d = 1. / ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+    const double S0 = d * ((X1 - X2) * (x1 - x2) + (Y1 - Y2) * (y1 - y2));
+    const double S1 = d * ((Y1 - Y2) * (x1 - x2) - (X1 - X2) * (y1 - y2));
+    const double S2 = d * ((Y1 - Y2) * (x1 * y2 - x2 * y1) - (X1 * y2 - X2 * y1) * (y1 - y2) - (X1 * x2 - X2 * x1) * (x1 - x2));
+    const double S3 = d * (-(X1 - X2) * (x1 * y2 - x2 * y1) - (Y1 * x2 - Y2 * x1) * (x1 - x2) - (Y1 * y2 - Y2 * y1) * (y1 - y2));
+    M[0] = S0; M[1] = -S1; M[2] = S2; M[3] = S1; M[4] = S0; M[5] = S3;
+}
+
+/* AffinePartial2DEstimatorCallback::computeError: squared reprojection error, f32 */
+static void similarity_errors(const float *src, const float *dst, int n, const double M[6], float *err)
+{
+    const float F0 = (float)M[0], F1 = (float)M[1], F2 = (float)M[2], F3 = (float)M[3], F4 = (float)M[4], F5 = (float)M[5];
+    for (int i = 0; i < n; ++i) {
+        const float fx = src[2 * i], fy = src[2 * i + 1];
+        const float a = F0 * fx + F1 * fy + F2 - dst[2 * i];
+        const float b = F3 * fx + F4 * fy + F5 - dst[2 * i + 1];
+        err[i] = a * a + b * b;
+    }
+}
+
+#define RFD_ORACLE_MAX_PTS 64
+/* the index pairs LMeDS samples for `n` points (at most `cap` pairs written); returns their number */
+RFD_API int rfd_oracle_lmeds_samples(int n, int *pairs, int cap)
+{
+    if (n <= 2) return 0;
+    int niters = rfd_oracle_cv_ransac_num_iters(0.99, 0.45, 2, 2000);
+    if (niters < 3) niters = 3;
+    uint64_t rng = 0xffffffffffffffffull; /* RNG rng((uint64)-1) */
+    int k = 0;
+    for (int it = 0; it < niters && k < cap; ++it) {
+        const int i0 = cv_rng_uniform(&rng, 0, n);
+        int i1;
+        do i1 = cv_rng_uniform(&rng, 0, n); while (i1 == i0);
+        pairs[2 * k] = i0; pairs[2 * k + 1] = i1;
+        ++k;
+    }
+    return k;
+}
+
+/* cv::estimateAffinePartial2D(src -> dst, LMEDS, 3.0, 2000, 0.99, 10) restated (see the block comment above).
+ * returns 1 and the 2x3 matrix, or 0: the reference's `transformation_matrix.empty()` branch.  inl (optional): the inlier mask */
+RFD_API int rfd_oracle_estimate_similarity_lmeds(const float *src, const float *dst, int n, double M[6], unsigned char *inl)
+{
+    unsigned char mask[RFD_ORACLE_MAX_PTS];
+    float err[RFD_ORACLE_MAX_PTS], srt[RFD_ORACLE_MAX_PTS];
+    if (n < 2 || n > RFD_ORACLE_MAX_PTS) return 0;
+    if (n == 2) { /* count == modelPoints: the kernel alone, every point an inlier, no refinement */
+        similarity_2pt(src, dst, 0, 1, M);
+        if (inl) inl[0] = inl[1] = 1;
+        return 1;
+    }
+    int pairs[2 * 64];
+    const int ns = rfd_oracle_lmeds_samples(n, pairs, 64);
+    double best[6] = {0, 0, 0, 0, 0, 0}, min_median = DBL_MAX;
+    for (int s = 0; s < ns; ++s) {
+        double Ms[6];
+        similarity_2pt(src, dst, pairs[2 * s], pairs[2 * s + 1], Ms);
+        similarity_errors(src, dst, n, Ms, err);
+        /* std::nth_element(errf.ptr<int>(), ... + count / 2, ...): the f32 errors ordered by their BIT PATTERNS as ints (they are
+         * >= +0, or NaN -- which then ranks above every number); the median is element count / 2 of that order */
+        for (int i = 0; i < n; ++i) srt[i] = err[i];
+        for (int i = 1; i < n; ++i) {
+            const float v = srt[i];
+            int32_t vb, jb;
+            memcpy(&vb, &v, 4);
+            int j = i - 1;
+            while (j >= 0 && (memcpy(&jb, &srt[j], 4), jb > vb)) { srt[j + 1] = srt[j]; --j; }
+            srt[j + 1] = v;
+        }
+        const double median = (double)srt[n / 2];
+        if (median < min_median) { min_median = median; memcpy(best, Ms, sizeof best); }
+    }
+    if (!(min_median < DBL_MAX)) return 0;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 2)) * sqrt(min_median);
+    if (!(sigma > 0.001)) sigma = 0.001;
+    const float t = (float)(sigma * sigma);
+    similarity_errors(src, dst, n, best, err);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) { mask[i] = err[i] <= t; cnt += mask[i]; }
+    if (inl) memcpy(inl, mask, (size_t)n);
+    if (cnt < 2) return 0;
+    memcpy(M, best, sizeof best);
+    double R[6];
+    if (similarity_ls(src, dst, n, mask, R)) memcpy(M, R, sizeof R); /* the fixed point of the LM refinement on the inliers */
+    return 1;
+}
+
+RFD_API int rfd_oracle_estimate_similarity(const float *src, const float *dst, int n, double M[6])
+{
+    return rfd_oracle_estimate_similarity_lmeds(src, dst, n, M, NULL);
+}
+
+/* the all-points closed form (rounds 1-3; what LMedS + refinement gives when every point is an inlier) */
+RFD_API int rfd_oracle_estimate_similarity_all_points(const float *src, const float *dst, int n, double M[6])
+{
+    return similarity_ls(src, dst, n, NULL, M);
 }
 
 static int cv_round_sat(double v) /* cv::saturate_cast<int>(double) = cvRound: nearest, ties to even */

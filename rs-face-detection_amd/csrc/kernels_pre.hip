@@ -147,12 +147,109 @@ int launch_tensor_to_nhwc4(const float *tensor, bf16_t *out, int n, int H, int W
 
 // ------------------------------------------------------------------------------------------------
 // FaceAlignment::call (face_alignment.rs:27-141).  Set-up: one thread per face estimates the 4-DOF similarity from
-// the five key points to the template in f64 (closed-form least squares -- the minimum the reference's LMEDS + LM
-// refinement converges to when all five points are inliers; documented divergence) and inverts it as
-// cv::warpAffine does; a degenerate point set takes the reference's crop + resize branch (:62-110, quirks kept).
+// the five key points to the template as cv::estimateAffinePartial2D(LMEDS, 3.0, 2000, 0.99, 10) does (:48-60; restated
+// from OpenCV 4.x calib3d ptsetreg.cpp as in oracle/rfd_oracle.c, where every step is cited): 13 two-point samples from a
+// cv::RNG re-seeded on every call (so the SAME index pairs for every face), the exact similarity through each pair in f64,
+// f32 squared errors, least median, inliers within 2.5 * 1.4826 * (1 + 5 / 3) * sqrt(median), then the least-squares
+// similarity over the inliers (the fixed point of the reference's 10 Levenberg-Marquardt iterations on this linear problem;
+// documented divergence ~1e-12).  Rounds 1-3 used the all-points closed form: no outlier rejection.  The matrix is then
+// inverted as cv::warpAffine does; no model (coincident points) takes the reference's crop + resize branch (:62-110,
+// quirks kept).
 // Warp: one thread per output pixel, cv::warpAffine's fixed-point coordinates (10 -> 5 fractional bits) and 15-bit
 // bilinear weights, out-of-image taps = 0.  Integer-exact against the oracle.
 // ------------------------------------------------------------------------------------------------
+constexpr int kLmedsIters = 13; // RANSACUpdateNumIters(0.99, 0.45, 2, 2000) = round(log(0.01) / log(1 - 0.55^2)); tests/test_oracle_cpu.py
+
+__device__ __forceinline__ unsigned cv_rng_next(unsigned long long &state) // cv::RNG: multiply-with-carry
+{
+    state = (unsigned long long)(unsigned)state * 4164903690u + (unsigned)(state >> 32);
+    return (unsigned)state;
+}
+
+__device__ void similarity_2pt(const float *src, const float *dst, int i0, int i1, double M[6])
+{
+    const double x1 = src[2 * i0], y1 = src[2 * i0 + 1], x2 = src[2 * i1], y2 = src[2 * i1 + 1];
+    const double X1 = dst[2 * i0], Y1 = dst[2 * i0 + 1], X2 = dst[2 * i1], Y2 = dst[2 * i1 + 1];
+    const double d = 1. / ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+    const double S0 = d * ((X1 - X2) * (x1 - x2) + (Y1 - Y2) * (y1 - y2));
+    const double S1 = d * ((Y1 - Y2) * (x1 - x2) - (X1 - X2) * (y1 - y2));
+    const double S2 = d * ((Y1 - Y2) * (x1 * y2 - x2 * y1) - (X1 * y2 - X2 * y1) * (y1 - y2) - (X1 * x2 - X2 * x1) * (x1 - x2));
+    const double S3 = d * (-(X1 - X2) * (x1 * y2 - x2 * y1) - (Y1 * x2 - Y2 * x1) * (x1 - x2) - (Y1 * y2 - Y2 * y1) * (y1 - y2));
+    M[0] = S0; M[1] = -S1; M[2] = S2; M[3] = S1; M[4] = S0; M[5] = S3;
+}
+
+__device__ void similarity_errors5(const float *src, const float *dst, const double M[6], float err[5])
+{
+    const float F0 = (float)M[0], F1 = (float)M[1], F2 = (float)M[2], F3 = (float)M[3], F4 = (float)M[4], F5 = (float)M[5];
+    for (int i = 0; i < 5; ++i) {
+        const float fx = src[2 * i], fy = src[2 * i + 1];
+        const float a = F0 * fx + F1 * fy + F2 - dst[2 * i];
+        const float b = F3 * fx + F4 * fy + F5 - dst[2 * i + 1];
+        err[i] = a * a + b * b;
+    }
+}
+
+// returns false: no model (the reference's empty matrix)
+__device__ bool estimate_similarity_lmeds5(const float *src, const float *dst, double M[6])
+{
+    unsigned long long rng = 0xffffffffffffffffull; // RNG rng((uint64)-1)
+    double best[6] = {0, 0, 0, 0, 0, 0}, min_median = 1.7976931348623157e308;
+    float err[5], srt[5];
+    for (int it = 0; it < kLmedsIters; ++it) {
+        const int i0 = (int)(cv_rng_next(rng) % 5u);
+        int i1;
+        do i1 = (int)(cv_rng_next(rng) % 5u); while (i1 == i0);
+        double Ms[6];
+        similarity_2pt(src, dst, i0, i1, Ms);
+        similarity_errors5(src, dst, Ms, err);
+        for (int i = 0; i < 5; ++i) srt[i] = err[i];
+        for (int i = 1; i < 5; ++i) {
+            const float v = srt[i];
+            int j = i - 1;
+            while (j >= 0 && __float_as_int(srt[j]) > __float_as_int(v)) { srt[j + 1] = srt[j]; --j; } // OpenCV orders the bit patterns
+            srt[j + 1] = v;
+        }
+        const double median = (double)srt[2];
+        if (median < min_median) {
+            min_median = median;
+            for (int k = 0; k < 6; ++k) best[k] = Ms[k];
+        }
+    }
+    if (!(min_median < 1.7976931348623157e308)) return false;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / 3) * sqrt(min_median);
+    if (!(sigma > 0.001)) sigma = 0.001;
+    const float t = (float)(sigma * sigma);
+    similarity_errors5(src, dst, best, err);
+    int cnt = 0;
+    bool use[5];
+    for (int i = 0; i < 5; ++i) { use[i] = err[i] <= t; cnt += use[i]; }
+    if (cnt < 2) return false;
+    for (int k = 0; k < 6; ++k) M[k] = best[k];
+    // least squares over the inliers
+    double msx = 0, msy = 0, mdx = 0, mdy = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!use[i]) continue;
+        msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
+        mdx += (double)dst[2 * i]; mdy += (double)dst[2 * i + 1];
+    }
+    msx /= cnt; msy /= cnt; mdx /= cnt; mdy /= cnt;
+    double sxx = 0, sa = 0, sb = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!use[i]) continue;
+        const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
+        const double xd = (double)dst[2 * i] - mdx, yd = (double)dst[2 * i + 1] - mdy;
+        sxx += xs * xs + ys * ys;
+        sa += xs * xd + ys * yd;
+        sb += xs * yd - ys * xd;
+    }
+    if (sxx > 0.0) {
+        const double a = sa / sxx, bb = sb / sxx;
+        M[0] = a; M[1] = -bb; M[2] = mdx - (a * msx - bb * msy);
+        M[3] = bb; M[4] = a; M[5] = mdy - (bb * msx + a * msy);
+    }
+    return true;
+}
+
 __device__ __forceinline__ int cv_round_sat(double v)
 {
     if (v >= 2147483647.0) return 2147483647;
@@ -174,23 +271,8 @@ __global__ void align_setup_kernel(AlignParams p)
         f.mode = -1; // landmarks = None: estimate_affine_partial_2d rejects the empty point set (:48)
     } else {
         const float *src = p.kps + (size_t)b * 10;
-        double msx = 0, msy = 0, mdx = 0, mdy = 0;
-        for (int i = 0; i < 5; ++i) {
-            msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
-            mdx += (double)p.std_lmk[2 * i]; mdy += (double)p.std_lmk[2 * i + 1];
-        }
-        msx /= 5; msy /= 5; mdx /= 5; mdy /= 5;
-        double sxx = 0, sa = 0, sb = 0;
-        for (int i = 0; i < 5; ++i) {
-            const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
-            const double xd = (double)p.std_lmk[2 * i] - mdx, yd = (double)p.std_lmk[2 * i + 1] - mdy;
-            sxx += xs * xs + ys * ys;
-            sa += xs * xd + ys * yd;
-            sb += xs * yd - ys * xd;
-        }
-        if (sxx > 0.0) {
-            const double a = sa / sxx, bb = sb / sxx;
-            double M[6] = {a, -bb, mdx - (a * msx - bb * msy), bb, a, mdy - (bb * msx + a * msy)};
+        double M[6];
+        if (estimate_similarity_lmeds5(src, p.std_lmk, M)) {
             double D = M[0] * M[4] - M[1] * M[3];
             D = D != 0 ? 1. / D : 0;
             const double A11 = M[4] * D, A22 = M[0] * D;

@@ -1,6 +1,6 @@
 """FaceAlignment on the device (face_alignment.rs:27-141) against the CPU oracle.
 Byte work -> bit-exact.  Parity against real OpenCV is unpinned (no OpenCV here; the reference's own test is
-commented out); the similarity estimate is the documented closed-form divergence from LMEDS + refinement."""
+commented out); the similarity estimate restates OpenCV's LMedS (oracle/rfd_oracle.c) on both sides."""
 import os
 
 import numpy as np
@@ -39,6 +39,30 @@ def test_random_similarities_match_oracle(det, oracle):
             want, st = oracle.face_alignment(f, box, kps)
             assert status[i] == st == 0
             assert np.array_equal(crops[i], want), (rnd, i)
+
+
+def test_outlier_landmarks_are_rejected_as_lmeds_does(det, oracle):
+    """estimate_affine_partial_2d(LMEDS) (face_alignment.rs:48-60): a landmark that disagrees with the other four is left out of
+    the model.  Device and oracle restate the same sample list, error arithmetic and inlier rule: byte-identical crops; and the
+    model is the least squares over exactly the points the oracle reports as inliers, never the displaced one."""
+    sizes = [(480, 640), (720, 1280), (1080, 1920), (300, 400), (640, 640)]
+    frames = [helpers.make_image(300 + i, h, w, n_blobs=6) for i, (h, w) in enumerate(sizes)]
+    for k in range(5):
+        sel = []
+        for i, (h, w) in enumerate(sizes):
+            kps, box = helpers.make_face_kps(500 + 7 * k + i, h, w)
+            kps[(k + i) % 5] += np.array([0.11 * w, -0.07 * h], np.float32)
+            sel.append((box, kps))
+        crops, status = det.align_faces(frames, sel)
+        for i, (f, (box, kps)) in enumerate(zip(frames, sel)):
+            want, st = oracle.face_alignment(f, box, kps)
+            assert status[i] == st == 0 and np.array_equal(crops[i], want), (k, i)
+            M, inl = oracle.estimate_similarity(kps, oracle.STANDARD_LANDMARKS, return_inliers=True)
+            assert not inl[(k + i) % 5] and inl.sum() >= 2
+            sub = oracle.estimate_similarity(kps[inl], oracle.STANDARD_LANDMARKS[inl], all_points=True)
+            assert np.abs(M - sub).max() < 1e-9
+            dragged = oracle.estimate_similarity(kps, oracle.STANDARD_LANDMARKS, all_points=True)   # rounds 1-3
+            assert np.abs(M - dragged).max() > 1e-3
 
 
 def test_other_template_sizes(det, oracle):

@@ -196,7 +196,7 @@ def test_face_selection_semantics(oracle):
 
 
 def test_alignment_similarity_and_warp(oracle):
-    """FaceAlignment restatement (face_alignment.rs:27-141): closed-form similarity + cv::warpAffine fixed point."""
+    """FaceAlignment restatement (face_alignment.rs:27-141): LMedS similarity + cv::warpAffine fixed point."""
     O = oracle
     # exact recovery of a known similarity
     th = np.deg2rad(-17.0)
@@ -222,6 +222,48 @@ def test_alignment_similarity_and_warp(oracle):
     out = O.warp_affine(img, np.array([[1, 0, 40.5], [0, 1, 0]], np.float64), 8, 48)
     assert not out[:, :40].any()
     assert np.array_equal(out[:, 40], (img[:8, 0].astype(np.int32) * 16384 + 16384) >> 15)
+
+
+def test_alignment_lmeds_restatement(oracle):
+    """cv::estimateAffinePartial2D(LMEDS, 3.0, 2000, 0.99, 10) as face_alignment.rs:48-60 calls it, restated from OpenCV 4.x
+    ptsetreg.cpp (parity unpinned: no OpenCV here).  Pins the restatement's own structure: the iteration count formula, the sample
+    list of the re-seeded cv::RNG, outlier rejection, the inlier rule, and what it reduces to when every point is an inlier."""
+    O = oracle
+    assert O.cv_ransac_num_iters(0.99, 0.45, 2, 2000) == 13              # what the device kernel hard-codes (kLmedsIters)
+    pairs = O.lmeds_samples(5)
+    assert pairs.shape == (13, 2) and (pairs[:, 0] != pairs[:, 1]).all() and pairs.min() >= 0 and pairs.max() <= 4
+    # regression pin of the restated multiply-with-carry sequence (state 2^64 - 1, coefficient 4164903690, draws modulo 5)
+    assert pairs.tolist() == [[0, 4], [0, 3], [1, 2], [1, 0], [3, 0], [0, 4], [1, 4], [3, 1], [0, 3], [0, 1], [0, 4], [4, 1], [0, 3]]
+    rng = np.random.default_rng(5)
+    tmpl = O.STANDARD_LANDMARKS
+    for trial in range(50):
+        th, sc = rng.uniform(-0.6, 0.6), rng.uniform(0.4, 3.0)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        Minv = np.hstack([sc * R, rng.uniform(50, 400, (2, 1))])          # template -> image
+        clean = (tmpl.astype(np.float64) @ Minv[:, :2].T + Minv[:, 2]).astype(np.float32)
+        M_clean, inl = O.estimate_similarity(clean, tmpl, return_inliers=True)
+        assert np.abs(clean @ M_clean[:, :2].T + M_clean[:, 2] - tmpl).max() < 2e-4
+        # one landmark far off: every sampled pair that avoids it reproduces the other four, so it is rejected whichever it is
+        k = trial % 5
+        bad = clean.copy()
+        bad[k] += np.float32(sc) * np.array([14.0, -9.0], np.float32)
+        M_bad, inl = O.estimate_similarity(bad, tmpl, return_inliers=True)
+        assert not inl[k] and inl.sum() == 4, (trial, inl)
+        assert np.abs(M_bad - M_clean).max() < 1e-3
+        M_all = O.estimate_similarity(bad, tmpl, all_points=True)       # rounds 1-3: dragged by the outlier
+        assert np.abs(M_all - M_clean).max() > 1e-2
+        # noisy but consistent points: the model is the least squares over whatever the inlier rule keeps (>= 3 of 5 here)
+        noisy = clean + rng.normal(0, 0.4 * sc, clean.shape).astype(np.float32)
+        M_n, inl = O.estimate_similarity(noisy, tmpl, return_inliers=True)
+        assert inl.sum() >= 2
+        sub = O.estimate_similarity(noisy[inl], tmpl[inl], all_points=True)
+        assert np.abs(M_n - sub).max() < 1e-9
+        if inl.all():
+            assert np.abs(M_n - O.estimate_similarity(noisy, tmpl, all_points=True)).max() < 1e-12
+    # two points: the kernel alone; coincident points: no model
+    M2 = O.estimate_similarity(clean[:2], tmpl[:2])
+    assert np.abs(clean[:2] @ M2[:, :2].T + M2[:, 2] - tmpl[:2]).max() < 1e-3
+    assert O.estimate_similarity(np.tile([[5.0, 6.0]], (5, 1)), tmpl) is None
 
 
 def test_alignment_branches_and_golden(oracle):
