@@ -178,9 +178,10 @@ __device__ void similarity_2pt(const float *src, const float *dst, int i0, int i
     M[0] = S0; M[1] = -S1; M[2] = S2; M[3] = S1; M[4] = S0; M[5] = S3;
 }
 
-__device__ void similarity_errors5(const float *src, const float *dst, const double M[6], float err[5])
+__device__ __forceinline__ void similarity_errors5(const float *src, const float *dst, const double M[6], float err[5])
 {
     const float F0 = (float)M[0], F1 = (float)M[1], F2 = (float)M[2], F3 = (float)M[3], F4 = (float)M[4], F5 = (float)M[5];
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
         const float fx = src[2 * i], fy = src[2 * i + 1];
         const float a = F0 * fx + F1 * fy + F2 - dst[2 * i];
@@ -189,12 +190,12 @@ __device__ void similarity_errors5(const float *src, const float *dst, const dou
     }
 }
 
-// returns false: no model (the reference's empty matrix)
+// returns false: no model (the reference's empty matrix).  Every array is indexed at compile time (no scratch: tests/test_build_cpu.py).
 __device__ bool estimate_similarity_lmeds5(const float *src, const float *dst, double M[6])
 {
     unsigned long long rng = 0xffffffffffffffffull; // RNG rng((uint64)-1)
     double best[6] = {0, 0, 0, 0, 0, 0}, min_median = 1.7976931348623157e308;
-    float err[5], srt[5];
+    float err[5];
     for (int it = 0; it < kLmedsIters; ++it) {
         const int i0 = (int)(cv_rng_next(rng) % 5u);
         int i1;
@@ -202,16 +203,15 @@ __device__ bool estimate_similarity_lmeds5(const float *src, const float *dst, d
         double Ms[6];
         similarity_2pt(src, dst, i0, i1, Ms);
         similarity_errors5(src, dst, Ms, err);
-        for (int i = 0; i < 5; ++i) srt[i] = err[i];
-        for (int i = 1; i < 5; ++i) {
-            const float v = srt[i];
-            int j = i - 1;
-            while (j >= 0 && __float_as_int(srt[j]) > __float_as_int(v)) { srt[j + 1] = srt[j]; --j; } // OpenCV orders the bit patterns
-            srt[j + 1] = v;
-        }
-        const double median = (double)srt[2];
+        // element 2 of the errors ordered by their bit patterns as ints (std::nth_element on errf.ptr<int>(): NaN above every number)
+        int e0 = __float_as_int(err[0]), e1 = __float_as_int(err[1]), e2 = __float_as_int(err[2]), e3 = __float_as_int(err[3]), e4 = __float_as_int(err[4]);
+#define RFD_CS(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+        RFD_CS(e0, e1) RFD_CS(e3, e4) RFD_CS(e2, e4) RFD_CS(e2, e3) RFD_CS(e1, e4) RFD_CS(e0, e3) RFD_CS(e0, e2) RFD_CS(e1, e3) RFD_CS(e1, e2)
+#undef RFD_CS
+        const double median = (double)__int_as_float(e2);
         if (median < min_median) {
             min_median = median;
+#pragma unroll
             for (int k = 0; k < 6; ++k) best[k] = Ms[k];
         }
     }
@@ -222,11 +222,14 @@ __device__ bool estimate_similarity_lmeds5(const float *src, const float *dst, d
     similarity_errors5(src, dst, best, err);
     int cnt = 0;
     bool use[5];
+#pragma unroll
     for (int i = 0; i < 5; ++i) { use[i] = err[i] <= t; cnt += use[i]; }
     if (cnt < 2) return false;
+#pragma unroll
     for (int k = 0; k < 6; ++k) M[k] = best[k];
     // least squares over the inliers
     double msx = 0, msy = 0, mdx = 0, mdy = 0;
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
         if (!use[i]) continue;
         msx += (double)src[2 * i]; msy += (double)src[2 * i + 1];
@@ -234,6 +237,7 @@ __device__ bool estimate_similarity_lmeds5(const float *src, const float *dst, d
     }
     msx /= cnt; msy /= cnt; mdx /= cnt; mdy /= cnt;
     double sxx = 0, sa = 0, sb = 0;
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
         if (!use[i]) continue;
         const double xs = (double)src[2 * i] - msx, ys = (double)src[2 * i + 1] - msy;
