@@ -116,7 +116,7 @@ typedef struct rfd_stats {
     float ms_d2h;
     float ms_total;
     int64_t candidates; /* rows with score >= threshold, summed over the batch */
-    int64_t detections; /* kept rows, summed over the batch */
+    int64_t detections; /* kept rows, summed over the batch (host-output entry points only: the device-resident ones leave the counts in HBM and do not read them back) */
     int64_t reserved[4];
 } rfd_stats;
 
