@@ -925,12 +925,23 @@ int rfd_debug_op_kernels(rfd_ctx *c, int n, int op, int co_running, char *names,
     const bool prof = c->net.profiling;
     c->net.co_running = co_running != 0;   // as for a chain of a split pass (batches >= 16 run as two chains of n / 2 images)
     c->net.profiling = false;
-    const int st = c->net.run(n, c->stream, op, op);
+    // the stem and the conv behind it may run as ONE launch when a pass runs them back to back (Network::run's peephole): ask for the
+    // pair, and report the conv as fused when the pair took a single launch
+    const auto &ops = c->net.g.ops;
+    const bool is_stem = ops[op].kind == OP_STEM && op + 1 < (int)ops.size(), after_stem = op > 0 && ops[op - 1].kind == OP_STEM;
+    const int st = c->net.run(n, c->stream, after_stem ? op - 1 : op, is_stem ? op + 1 : op);
     c->net.co_running = saved;
     c->net.profiling = prof;
     note.dry = false;
     RFD_TRY(st);
-    snprintf(names, (size_t)cap, "%s", note.names.c_str());
+    std::string out = note.names;
+    if (is_stem || after_stem) {
+        const size_t cut = out.find(" + ");
+        const bool fused = cut == std::string::npos; // one launch for the two ops
+        if (is_stem) out = fused ? out : out.substr(0, cut);
+        else out = fused ? "(fused into " + out + ")" : out.substr(cut + 3);
+    }
+    snprintf(names, (size_t)cap, "%s", out.c_str());
     return RFD_OK;
 }
 

@@ -192,8 +192,11 @@ int launch_conv_b2b_s1(const B2BParams &p, hipStream_t s);
 int launch_conv0(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H,
                  int W, hipStream_t s);
 // fused stem: conv0 (7x7/2 + bias + ReLU) -> 3x3/2 max pool -> affine + ReLU, NHWC4 in, [B][H/4][W/4][64] out
+// w1 / bias1 / t1 / fused (all or none): the first unit's conv1 (1x1, 64 -> 64, bias + ReLU) computed on the pooled tile and stored to
+// t1 when the persistent form runs; *fused tells the caller whether it was (then the conv's own op must not run)
 int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const float *scale, const float *shift,
-                bf16_t *y, int B, int H, int W, hipStream_t s);
+                bf16_t *y, int B, int H, int W, hipStream_t s, const bf16_t *w1 = nullptr, const float *bias1 = nullptr,
+                bf16_t *t1 = nullptr, bool *fused = nullptr);
 // MobileNet-0.25 helpers: first 3x3/2 conv (3 -> 8 real channels, output padded to Cd) and depthwise 3x3
 int launch_first3x3(const bf16_t *x4, const bf16_t *w, const float *bias, bf16_t *y, int B, int H, int W, int Cd,
                     hipStream_t s);

@@ -3350,14 +3350,23 @@ __global__ void __launch_bounds__(256) stem_kernel(const bf16_t *__restrict__ x4
 // across tiles (the one-tile kernel re-reads 28 KiB of weights from L2 per 64 pooled pixels), and the NEXT tile's input patch is
 // requested into registers before the conv phase and written to LDS behind it, so its latency hides under the MFMAs instead of
 // opening every tile.  Same arithmetic per tile: bit-identical output.
+// FUSE1 (round 4): the first unit's conv1 (1x1, 64 -> 64, + bias, ReLU) rides on the pooled tile.  The pooling pass maps a lane to
+// (pooled pixel = lane & 15 of the wave's pooled row, channel group = lane >> 4 [+ 4 in the second round]) -- the B-fragment layout
+// of the 16 x 16 x 32 MFMA -- so the packed bf16 outputs it stores to y ARE conv1's operand; W1 (8 KiB) sits in LDS, 8 MFMAs per
+// wave and tile, and t1 = relu(W1 . y + b1) is stored next to y.  Same operand bits, same two K steps on a zero accumulator, same
+// epilogue arithmetic as the generic kernel on the stored y: bit-identical, and y is not read back (105 MB per 32 images).
+template <bool FUSE1>
 __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__restrict__ x4, const bf16_t *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ scale,
                                                               const float *__restrict__ shift, bf16_t *__restrict__ y, int H,
-                                                              int W, int tiles_w, int tiles_h, int ntiles, int per)
+                                                              int W, int tiles_w, int tiles_h, int ntiles, int per,
+                                                              const bf16_t *__restrict__ w1, const float *__restrict__ bias1,
+                                                              bf16_t *__restrict__ t1)
 {
     RFD_CLOCK(12);
     __shared__ __attribute__((aligned(16))) uint2 in_tile[kStemIR * kStemIP];
     __shared__ __attribute__((aligned(16))) bf16_t conv_tile[kStemCR * kStemCC * kStemCP];
+    __shared__ __attribute__((aligned(16))) bf16_t w1_tile[FUSE1 ? 64 * 64 : 8]; // row rho = i*16 + r holds output channel (i>>1)*32 + (r>>2)*8 + (i&1)*4 + (r&3); 16-byte chunk c at (c ^ (rho & 7))
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
     // scalar wave index: the loops over `wave` below are then scalar loops in the ISA, i.e. their 128-bit LDS reads provably
     // run with EXEC all ones (tools/isa_check.py, tests/test_build_cpu.py)
@@ -3405,6 +3414,14 @@ __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__re
     uint2 pre[NR];
     load_patch(t_begin, pre);
     store_patch(pre);
+    if (FUSE1) {
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const int idx = tid + round * 256, rho = idx >> 3, c = idx & 7, i = rho >> 4, r = rho & 15;
+            const int chn = (i >> 1) * 32 + (r >> 2) * 8 + (i & 1) * 4 + (r & 3);
+            *reinterpret_cast<uint4 *>(w1_tile + rho * 64 + ((c ^ (rho & 7)) << 3)) = *reinterpret_cast<const uint4 *>(w1 + chn * 64 + c * 8);
+        }
+    }
     __syncthreads();
 
     float bv[2][8];
@@ -3458,9 +3475,11 @@ __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__re
         if (more) store_patch(pre);
     // 3x3/2 max pool over the conv tile, then affine + ReLU; 8 channels (16 bytes) per item
     static_assert(kStemPH * kStemPW * 8 % 256 == 0, "the pooling pass runs whole rounds of the workgroup (a scalar trip count)");
+    static_assert(!FUSE1 || (kStemPW == 16 && kStemPH == 4), "fused conv1: a wave owns one pooled row of 16 pixels");
+    uint4 yq[2]; // FUSE1: this lane's B fragments -- channels (round * 4 + fq) * 8 .. + 7 of pooled pixel (wave, frow)
     for (int round = 0; round < kStemPH * kStemPW * 8 / 256; ++round) {
         const int item = tid + round * 256;
-        const int c8 = item & 7, pp = item >> 3;
+        const int c8 = FUSE1 ? round * 4 + fq : item & 7, pp = FUSE1 ? wave * 16 + frow : item >> 3;
         const int pr = pp / kStemPW, pc = pp - pr * kStemPW;
         // no early `continue`: the ds_read_b128 below must run with EXEC all ones ("a hardware
         // observation": 128-bit LDS reads under a partial EXEC mask return wrong data in lanes 48-63 while MFMA waves of
@@ -3497,6 +3516,36 @@ __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__re
         const uint2 hi = pack_bf16x4(fmaxf(mx[4] * s1.x + t1.x, 0.f), fmaxf(mx[5] * s1.y + t1.y, 0.f),
                                      fmaxf(mx[6] * s1.z + t1.z, 0.f), fmaxf(mx[7] * s1.w + t1.w, 0.f));
         if (live) *reinterpret_cast<uint4 *>(y + (((size_t)b * Hp + ph0 + pr) * Wp + pw0 + pc) * 64 + c8 * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (FUSE1) yq[round & 1] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    if (FUSE1) { // conv1 on the pooled row of this wave: t1[pixel][n] = relu(sum_k W1[n][k] y[pixel][k] + b1[n])
+        f32x4 a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 bq = __builtin_bit_cast(bf16x8, yq[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rho = i * 16 + frow;
+                const bf16x8 aw = *reinterpret_cast<const bf16x8 *>(w1_tile + rho * 64 + (((kk * 4 + fq) ^ (rho & 7)) << 3));
+                a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bq, a1[i], 0, 0, 0);
+            }
+        }
+        const bool live1 = ph0 + wave < Hp && pw0 + frow < Wp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 c0 = *reinterpret_cast<const float4 *>(bias1 + h * 32 + fq * 8), c1 = *reinterpret_cast<const float4 *>(bias1 + h * 32 + fq * 8 + 4);
+            const float b1v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = fmaxf(a1[2 * h][k] + b1v[k], 0.f);
+                o[4 + k] = fmaxf(a1[2 * h + 1][k] + b1v[4 + k], 0.f);
+            }
+            const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
+            if (live1) *reinterpret_cast<uint4 *>(t1 + (((size_t)b * Hp + ph0 + wave) * Wp + pw0 + frow) * 64 + h * 32 + fq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
     }
         __syncthreads();                                  // next patch in LDS, conv tile free
     }
@@ -3504,8 +3553,9 @@ __global__ void __launch_bounds__(256) stem_persistent_kernel(const bf16_t *__re
 
 
 int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const float *scale, const float *shift,
-                bf16_t *y, int B, int H, int W, hipStream_t s)
+                bf16_t *y, int B, int H, int W, hipStream_t s, const bf16_t *w1, const float *bias1, bf16_t *t1, bool *fused)
 {
+    if (fused) *fused = false;
     if ((H | W) & 3) {
         set_error("stem: input %dx%d must be a multiple of 4", H, W);
         return RFD_ERR_INVALID_ARG;
@@ -3519,8 +3569,15 @@ int launch_stem(const bf16_t *x4, const bf16_t *w, const float *bias, const floa
     const int slots = 2 * device_cus();
     if (persist_env && ntiles >= 4 * slots) {
         const int per = ceil_div(ntiles, slots), grid = ceil_div(ntiles, per);
-        if (note_launch("stem_persistent_kernel")) return RFD_OK;
-        hipLaunchKernelGGL(stem_persistent_kernel, dim3((unsigned)grid), dim3(256), 0, s, x4, w, bias, scale, shift, y, H, W, tiles_w, tiles_h, ntiles, per);
+        if (w1 && t1 && fused) { // the first unit's conv1 on the pooled tile (Network::run offers it when the next op is that conv)
+            *fused = true;
+            if (note_launch("stem_persistent_kernel<true>")) return RFD_OK;
+            hipLaunchKernelGGL(stem_persistent_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, x4, w, bias, scale, shift, y, H, W, tiles_w, tiles_h, ntiles, per, w1, bias1, t1);
+            RFD_HIP(hipGetLastError());
+            return RFD_OK;
+        }
+        if (note_launch("stem_persistent_kernel<false>")) return RFD_OK;
+        hipLaunchKernelGGL(stem_persistent_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, x4, w, bias, scale, shift, y, H, W, tiles_w, tiles_h, ntiles, per, nullptr, nullptr, nullptr);
         RFD_HIP(hipGetLastError());
         return RFD_OK;
     }

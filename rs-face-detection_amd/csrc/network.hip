@@ -768,8 +768,25 @@ int Network::run(int B, hipStream_t s, int first_op, int last_op, int batch_off,
             RFD_TRY(launch_dwconv3x3((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, (bf16_t *)tensor_ptr(o.out, batch_off), B,
                                      tin.H, tin.W, tin.C, L.stride, s));
         } else if (o.kind == OP_STEM) {
+            // Peephole (round 4): when the next op of the range is the first unit's conv1 -- a plain 1x1 64 -> 64 conv + bias + ReLU
+            // on the stem's output -- the persistent stem kernel computes it on the pooled tile (launch_stem decides whether that
+            // form runs); the conv's own op is then skipped.  Bit-identical (tests/test_persistent_gpu.py); RFD_STEM_FUSE=0: never.
+            static const int fuse_env = [] { const char *e = getenv("RFD_STEM_FUSE"); return e ? atoi(e) : 1; }();
+            const bf16_t *w1 = nullptr; const float *b1 = nullptr; bf16_t *t1 = nullptr;
+            if (fuse_env && !profiling && force_tile == 0 && i + 1 <= last_op && skip_ops.empty()) {
+                const Op &n = g.ops[i + 1];
+                const Layer &Ln = g.layers[n.layer];
+                const bool plain = n.kind == OP_CONV && n.in == o.out && Ln.kh == 1 && Ln.kw == 1 && Ln.stride == 1 && Ln.cin_d == 64 &&
+                                   Ln.cout_d == 64 && n.relu && n.in_affine < 0 && n.res < 0 && n.layer2 < 0 && n.layer_n2 < 0 && n.out2 < 0 &&
+                                   n.outf < 0 && n.out >= 0 && n.x_coff == 0 && n.y_coff == 0 && n.branch == o.branch &&
+                                   g.tensors[n.out].C == 64 && n.n_valid >= 64 && n.y_split >= 64;
+                if (plain) { w1 = d_w + Ln.w_off; b1 = d_b + Ln.b_off; t1 = (bf16_t *)tensor_ptr(n.out, batch_off); }
+            }
+            bool fused = false;
             RFD_TRY(launch_stem((const bf16_t *)tensor_ptr(o.in, batch_off), d_w + L.w_off, d_b + L.b_off, d_b + g.b_total + L.a_off,
-                                d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s));
+                                d_b + g.b_total + L.a_off + L.cout_d, (bf16_t *)tensor_ptr(o.out, batch_off), B, tin.H, tin.W, s, w1, b1, t1,
+                                w1 ? &fused : nullptr));
+            if (fused) ++i; // the conv ran inside the stem kernel
         } else if (o.kind == OP_B2B && L.cin_d == 64 && g.layers[o.layer_b].cout_d == 64) {
             const Layer &Lb = g.layers[o.layer_b];
             B2BParams bp;

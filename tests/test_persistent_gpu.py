@@ -201,7 +201,8 @@ def test_persistent_stem_equals_one_tile_stem_bitwise(rfd, size):
     x = rng.integers(0, 256, size=(nb, tin.height, tin.width, tin.channels)).astype(np.float32)
     x[..., 3] = 0
     bits = (x.view(np.uint32) >> 16).astype(np.uint16)        # small integers are exact in bf16
-    assert det.debug_op_kernels(nb, op) == ["stem_persistent_kernel"] and det.debug_op_kernels(2, op) == ["stem_kernel"]
+    # (introspection answers for a real pass, where the conv behind the stem rides in the persistent kernel: <true>)
+    assert det.debug_op_kernels(nb, op) == ["stem_persistent_kernel<true>"] and det.debug_op_kernels(2, op) == ["stem_kernel"]
     want = []
     for i in range(0, nb, 2):
         det.debug_write(o.in_, bits[i:i + 2])
@@ -214,4 +215,41 @@ def test_persistent_stem_equals_one_tile_stem_bitwise(rfd, size):
         det.debug_run(n, op, op)
         got = det.debug_read(o.out, n, tout)
         assert np.array_equal(got, want[:n]), "n = %d: %d elements differ" % (n, int((got != want[:n]).sum()))
+    det.close()
+
+
+@pytest.mark.parametrize("size", [(640, 640), (480, 352)])
+def test_stem_with_the_first_conv1_fused_equals_the_two_ops_bitwise(rfd, size):
+    """Round 4: when a pass runs the stem and the first unit's conv1 (1x1, 64 -> 64, bias + ReLU) back to back, the persistent stem
+    kernel computes the conv on its pooled tile (the pooling pass's lane layout IS the MFMA's B-fragment layout) and the conv's own
+    launch is skipped.  Against the two ops run one at a time (the stem alone, then the generic conv kernel on the stored output):
+    both tensors bit-identical, including partial tiles on both edges (480 x 352) and a short last run of tiles."""
+    nb = 16 if size == (640, 640) else 40
+    det = rfd.RetinaFaceDetection(image_size=size, max_batch_size=nb, max_det=16)
+    det.init_synthetic_weights(1234)
+    g = rfd.Graph(rfd.BACKBONE_R50, size[0], size[1])
+    op = next(i for i, o in enumerate(g.ops) if o.kind == 3)
+    o, o1 = g.ops[op], g.ops[op + 1]
+    L1 = g.layers[o1.layer]
+    assert o1.kind == 2 and o1.in_ == o.out and (L1.kh, L1.cin, L1.cout) == (1, 64, 64)
+    tin, ty, tt = g.tensors[o.in_], g.tensors[o.out], g.tensors[o1.out]
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, 256, size=(nb, tin.height, tin.width, tin.channels)).astype(np.float32)
+    x[..., 3] = 0
+    bits = (x.view(np.uint32) >> 16).astype(np.uint16)
+    poison = lambda n, t: np.full((n, t.height, t.width, t.channels), 0x7fc0, np.uint16)
+    assert det.debug_op_kernels(nb, op + 1) == ["(fused into stem_persistent_kernel<true>)"]
+    assert det.debug_op_kernels(2, op + 1)[0].startswith("conv_igemm_kernel")      # below the persistent stem's threshold: its own launch
+    for n in ((16, 7) if nb == 16 else (40, 37)):
+        det.debug_write(o.in_, bits[:n])
+        det.debug_write(o.out, poison(n, ty)); det.debug_write(o1.out, poison(n, tt))
+        det.debug_run(n, op, op)            # one op at a time: nothing to fuse
+        det.debug_run(n, op + 1, op + 1)
+        want_y, want_t = det.debug_read(o.out, n, ty), det.debug_read(o1.out, n, tt)
+        det.debug_write(o.out, poison(n, ty)); det.debug_write(o1.out, poison(n, tt))
+        det.debug_run(n, op, op + 1)        # the range: the fused kernel
+        got_y, got_t = det.debug_read(o.out, n, ty), det.debug_read(o1.out, n, tt)
+        assert np.array_equal(got_y, want_y), "n = %d: stem output differs in %d elements" % (n, int((got_y != want_y).sum()))
+        assert np.array_equal(got_t, want_t), "n = %d: conv1 output differs in %d elements" % (n, int((got_t != want_t).sum()))
+        assert not (got_t == 0x7fc0).any()
     det.close()

@@ -58,6 +58,9 @@ for rnd in range(a.rounds):
         for tile in tiles:
             det.debug_set_conv_tile(tile)
             for op in ops:
+                if det.debug_op_kernels(B, op)[0].startswith("(fused"):   # runs inside the previous op's kernel in a real pass
+                    res.setdefault((B, tile, op), []).append(0.0)
+                    continue
                 det.debug_run(B, op, op)
                 ts = []
                 for _ in range(a.reps):
@@ -75,5 +78,5 @@ for B in batches:
             tot[t] += v
         fl = 2.0 * o.macs * B
         print("%3d %-22s k%d %4d->%4d  " % (op, L.name.decode(), L.kh, L.cin, L.cout) +
-              "  ".join("%7.1f us %6.0f TF" % (v, fl / v / 1e6) for v in row))
+              "  ".join(("%7.1f us %6.0f TF" % (v, fl / v / 1e6)) if v > 0 else "    (fused into the stem)" for v in row))
     print("    totals", {t: round(v, 1) for t, v in tot.items()})

@@ -28,8 +28,15 @@ def tbytes(t, ch=None):
 kmap = json.load(open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "op_kernels_latest.json")))["ops"]
 
 
+def fused_into(i):
+    """the op runs inside the previous op's kernel in a real pass (the stem with the first conv1): its input is not read back"""
+    return kmap[str(i)]["kernels"][0].startswith("(fused into ")
+
+
 def op_class(i):
     ks = kmap[str(i)]["kernels"]
+    if fused_into(i):
+        return "rfd::" + ks[0][len("(fused into "):].rstrip(")").split("<")[0]
     return "rfd::" + ks[0].split("<")[0] if len(ks) == 1 else " + ".join("rfd::" + k.split("<")[0] for k in ks)
 
 
@@ -41,6 +48,8 @@ for i, o in enumerate(g.ops):
         continue
     k = op_class(i).replace("conv_b2b_s1_persistent_k128_kernel", "conv_b2b_s1_kernel").replace("conv_b2b_s1_persistent_kernel", "conv_b2b_s1_kernel")
     rd = tbytes(o.in_, max(L.cin, 64) if (o.kind == 2 and g.tensors[o.in_].channels > max(L.cin, 64)) else None) + (tbytes(o.in2) // (g.layers[o.layer2].stride ** 2) if o.layer2 >= 0 else 0) + tbytes(o.res)  # a stride-2 shortcut reads every other pixel of every other row
+    if fused_into(i):
+        rd = 0
     wr = 0
     for t in (o.out, o.out2, o.outf, o.out_b):
         if t >= 0:
