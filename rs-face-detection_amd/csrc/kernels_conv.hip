@@ -1426,6 +1426,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64, 2) conv3x3_kx_kernel(co
 // chunk swizzle keyed on hx & 7, so the XOR of a tap depends on kx only.  LDS: 72 KiB + 2 x 41 KiB = 154 KiB, 1 workgroup / CU.
 // ------------------------------------------------------------------------------------------------
 constexpr int kC64T = 16, kC64H = kC64T + 2, kC64HP = 41 /* pieces of 8 rows */;
+#ifndef RFD_C64_EXP
+#define RFD_C64_EXP 0 // timing experiments (tools/build_variant.sh; results are garbage): 1 no halo DMA after the first tile, 2 no output stores, 3 neither, 4 neither + no MFMAs
+#endif
 __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, int tiles_x, int tiles_y)
 {
     RFD_CLOCK(5);
@@ -1498,7 +1501,9 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, in
         // previous tile's stores were issued); the other buffer is free
         if (tile == (int)blockIdx.x) wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* no LDS read in flight at a barrier that frees a ring slot for DMA (tools/isa_check.py) */
+#if RFD_C64_EXP == 0 || RFD_C64_EXP == 2
         if (next < ntiles) stage_halo(next, buf ^ 1);
+#endif
         const bf16_t *xb = xbase + buf * (kC64HP * 512);
         f32x4 acc[2][4];
 #pragma unroll
@@ -1547,7 +1552,11 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(const ConvParams p, in
             const uint2 lo = pack_bf16x4(o[0], o[1], o[2], o[3]), hi = pack_bf16x4(o[4], o[5], o[6], o[7]);
             typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
             const uint32_t yoff = (uint32_t)(((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + p.y_coff + wn * 32 + fq * 8) * 2);
+#if RFD_C64_EXP == 0 || RFD_C64_EXP == 1
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, (oy < p.H && ox < p.W) ? yoff : kOob, 0, 0);
+#else
+            if (lo.x == 0x12345678u && tile < 0) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, ry, yoff, 0, 0); // keeps the values live
+#endif
         }
         buf ^= 1;
     }
