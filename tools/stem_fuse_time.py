@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Host-timed cost of the stem + the first unit's conv1 at 16 images: as the range (0, 1) of one pass (the persistent stem kernel runs the
+conv on its pooled tile) against the two ops one at a time (two launches), and the stem alone.  Every figure carries the same per-call
+host overhead (debug_run synchronises), so only the differences mean anything.  usage: python tools/stem_fuse_time.py"""
 import os, sys, time
 sys.path.insert(0, "/root/repo/rs-face-detection_amd/python"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, rfd_hip as rfd
